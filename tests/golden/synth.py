@@ -1,0 +1,80 @@
+"""Deterministic synthetic inputs shared by make_golden.py (which feeds them to the reference)
+and by the tests (which feed the same arrays to the oracle and to the HIP path).
+
+Everything comes from numpy's legacy ``RandomState`` (MT19937 + polar normal), whose stream
+is frozen across numpy versions, computed in float64 and rounded once -- so the build
+container and the GPU box regenerate bit-identical inputs and the big tensors need not
+be stored in the fixtures.  Large outputs are stored as *fingerprints* (a seeded sample of
+entries plus sums) to keep fixtures small.
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+
+def _seed(tag: str) -> int:
+    return zlib.crc32(tag.encode()) & 0x7FFFFFFF
+
+
+def normal(tag: str, shape, scale: float = 1.0, dtype=np.float32) -> np.ndarray:
+    return (np.random.RandomState(_seed(tag)).standard_normal(tuple(shape)) * scale).astype(dtype)
+
+
+def uniform(tag: str, shape, dtype=np.float32) -> np.ndarray:
+    return np.random.RandomState(_seed(tag)).random_sample(tuple(shape)).astype(dtype)
+
+
+def integers(tag: str, shape, high: int) -> np.ndarray:
+    return np.random.RandomState(_seed(tag)).randint(0, high, size=tuple(shape)).astype(np.int64)
+
+
+def probs(tag: str, shape, dtype=np.float32, temperature: float = 1.0) -> np.ndarray:
+    """Per-pixel simplex along axis 1 (softmax of a normal field), float64 math, one rounding."""
+    z = np.random.RandomState(_seed(tag)).standard_normal(tuple(shape)) / temperature
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    return (e / e.sum(axis=1, keepdims=True)).astype(dtype)
+
+
+def mask(tag: str, shape, keep: float = 0.7) -> np.ndarray:
+    return (np.random.RandomState(_seed(tag)).random_sample(tuple(shape)) < keep).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- fingerprints
+MAX_SAMPLE = 2048
+
+
+def sample_index(numel: int, tag: str) -> np.ndarray:
+    if numel <= MAX_SAMPLE:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(_seed("idx/" + tag)).choice(numel, MAX_SAMPLE, replace=False))
+
+
+def fingerprint(arr, tag: str) -> dict:
+    """{'shape', 'sample', 'sum', 'abssum'} of an array (sample = entries at sample_index)."""
+    a = np.asarray(arr)
+    flat = a.reshape(-1).astype(np.float64)
+    return {"shape": np.asarray(a.shape, dtype=np.int64), "sample": flat[sample_index(flat.size, tag)],
+            "sum": np.float64(flat.sum()), "abssum": np.float64(np.abs(flat).sum())}
+
+
+def check_fingerprint(arr, fp: dict, tag: str, rtol: float, atol: float) -> None:
+    """Assert ``arr`` matches a stored fingerprint; tolerances are relative to the entry scale."""
+    a = np.asarray(arr)
+    assert tuple(a.shape) == tuple(int(v) for v in fp["shape"]), (tag, a.shape, fp["shape"])
+    flat = a.reshape(-1).astype(np.float64)
+    got = flat[sample_index(flat.size, tag)]
+    np.testing.assert_allclose(got, fp["sample"], rtol=rtol, atol=atol, err_msg=f"sample mismatch: {tag}")
+    scale = float(fp["abssum"]) + 1e-30
+    assert abs(flat.sum() - float(fp["sum"])) <= rtol * scale * 4 + atol * flat.size, \
+        (tag, flat.sum(), float(fp["sum"]), scale)
+
+
+def fp_pack(prefix: str, fp: dict) -> dict:
+    return {f"{prefix}#{k}": v for k, v in fp.items()}
+
+
+def fp_unpack(npz, prefix: str) -> dict:
+    return {k: npz[f"{prefix}#{k}"] for k in ("shape", "sample", "sum", "abssum")}
