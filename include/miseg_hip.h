@@ -1,0 +1,221 @@
+/*
+ * miseg_hip.h -- C ABI of the MI355X (gfx950) hot path of the semi-supervised segmentation
+ * train step (2D U-Net + global/local IIC mutual information + UDA consistency).
+ *
+ * The reference (jizongFox/MI-based-Regularized-Semi-supervised-Segmentation) is pure Python
+ * on stock PyTorch: it has NO native/FFI layer.  The seam this library sits under is therefore
+ * the reference's Python object API; every entry point below names the
+ * reference call site whose ATen op sequence it replaces ("ref:" = path:line in the reference
+ * checkout, "whl:" = inside its vendored deepclustering2 wheel).
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ *     owned by the caller (PyTorch allocates; the library never allocates user-visible memory).
+ *   - `stream` is a hipStream_t passed as void*; every launch goes on it; no internal threads,
+ *     no host synchronisation, so calls may be captured into a hipGraph.
+ *   - Return value: 0 = ok, <0 = error (MISEG_E_*).  miseg_last_error() gives the message of
+ *     the last failure on the calling thread.  Nothing throws.
+ *   - `dt` selects the storage/operand type of U-Net activations and packed weights:
+ *     MISEG_F32 (exact fp32, v_mfma_f32_16x16x4_f32) or MISEG_BF16 (bf16 operands,
+ *     v_mfma_f32_16x16x32_bf16, fp32 accumulate).  Statistics, losses, probabilities,
+ *     gradients of parameters and the optimiser are always fp32.
+ *   - U-Net activations are NHWC ("channels last"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c.
+ *     Probability maps handed to the local-MI kernels are NCHW fp32 (the reference layout).
+ *   - `flips` = int32[N] per-sample bit mask, bit0 = flip H, bit1 = flip W: the decisions the
+ *     reference draws from Python's `random` under FixRandomSeed (ref: semi_seg/epocher.py:148-149,
+ *     whl:deepclustering2/augment/tensor_augment.py:31-39).  The host draws; kernels only apply.
+ *   - Scratch ("ws") sizes come from the matching *_ws_bytes() query.
+ */
+#ifndef MISEG_HIP_H
+#define MISEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISEG_F32 0
+#define MISEG_BF16 1
+
+#define MISEG_OK 0
+#define MISEG_E_INVALID (-1) /* bad argument (shape, dtype, null pointer, unsupported size) */
+#define MISEG_E_LAUNCH (-2)  /* HIP launch failure; see miseg_last_error() */
+
+int miseg_version(void);
+const char* miseg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Local (displacement-window) IIC mutual information
+ * ref: contrastyou/losses/iic_loss.py:107-149 (IIDSegmentationLoss.__call__),
+ *      :152-189 (patch_generator / IIDSegmentationSmallPathLoss).
+ * x, y: fp32 NCHW [N,K,H,W] per-pixel simplexes.  `win` = int32[P][4] windows (h0,h1,w0,w1) in
+ * reference iteration order; each window is treated as an independent zero-padded map exactly
+ * like the reference's crop (:158) followed by conv2d(padding=pad) (:123).  mask: fp32 [N,1,H,W]
+ * or NULL (:115-117).
+ * joint_fwd : raw[P][T][T][K][K] (T = 2*pad+1), raw[p][a][b][i][j] =
+ *             sum_{n,h,w} Xpad[n,i,h+a,w+b] * Y[n,j,h,w]              (the conv2d at :120-123)
+ * loss_fwd  : per window: global-min shift +1e-16 (:124), per-displacement normalise (:129),
+ *             symmetrise (:132), marginals (:135-136), -sum P(logP - lam logPi - lam logPj)/T^2
+ *             (:139-146).  Writes loss[P] and grad_raw[P][T][T][K][K] = d loss[p] / d raw[p].
+ * bwd       : gx, gy [N,K,H,W] += sum_p scale[p] * (d loss[p]/d x, y) through the joint and mask.
+ *             scale = fp32[P] DEVICE array (upstream grad / P, the average_iter at :186).
+ *             gx, gy must be zero-initialised by the caller when accumulate == 0 is not used.
+ * ------------------------------------------------------------------------------------------ */
+int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P);
+int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, const float* mask, int64_t N,
+                              int64_t K, int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
+                              float* raw, void* ws, int64_t ws_bytes);
+int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
+                             float* loss, float* grad_raw);
+int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
+                        int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
+                        const float* grad_raw, const float* scale, float* gx, float* gy);
+
+/* ------------------------------------------------------------------------------------------
+ * Global IIC mutual information, S sub-heads in one launch
+ * ref: contrastyou/losses/iic_loss.py:43-71 (IIDLoss.forward), :74-94 (compute_joint);
+ *      wrapper semi_seg/_utils.py:12-15.
+ * x, y: fp32 [S][N][K].  Outputs loss[S], loss_no_lamb[S], joint[S][K][K] and, for backward,
+ * gx, gy [S][N][K] = upstream[s] * d loss[s]/d x,y  (upstream = fp32[S] device array).
+ * ------------------------------------------------------------------------------------------ */
+int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K,
+                         float lamb, float* loss, float* loss_no_lamb, float* joint);
+int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K,
+                         float lamb, const float* upstream, float* gx, float* gy);
+
+/* ------------------------------------------------------------------------------------------
+ * Cluster heads
+ * ref: contrastyou/trainer/_utils.py:137-168 (LocalClusterHead: 1x1 conv C->K + bias, channel
+ *      softmax, x S sub-heads) and :96-134 (ClusterHead: global avg pool, Linear C->K, softmax).
+ * The flip replay of the tapped feature (ref: semi_seg/epocher.py:264-266) and the
+ * cat([features_tf, tf_features]) (:269-271) are index math here: sample m of the output reads
+ * feature sample src[m] (int32[M]) with flip mask flips[m].
+ * feat: NHWC [B,H,W,C] (dt).  w: fp32 [S][K][C], b: fp32 [S][K].  T = softmax temperature.
+ * local  fwd: prob fp32 [S][M][K][H][W] (NCHW per sub-head).
+ * local  bwd: gprob same shape -> gfeat NHWC [B,H,W,C] (dt, ACCUMULATES into existing values),
+ *             gw [S][K][C], gb [S][K] (overwritten).
+ * global fwd: prob fp32 [S][M][K]; bwd likewise (flips are irrelevant under global pooling).
+ * ------------------------------------------------------------------------------------------ */
+int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                         const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b,
+                         int64_t S, int64_t K, float T, float* prob);
+int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K);
+int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                         const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S,
+                         int64_t K, float T, const float* prob, const float* gprob, void* gfeat, float* gw,
+                         float* gb, void* ws, int64_t ws_bytes);
+int miseg_head_global_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                          const int32_t* src, int64_t M, const float* w, const float* b, int64_t S, int64_t K,
+                          float T, float* pooled, float* prob);
+int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
+                          int64_t M, const float* w, int64_t S, int64_t K, float T, const float* pooled,
+                          const float* prob, const float* gprob, void* gfeat, float* gw, float* gb,
+                          float* dz_ws /* fp32[S*M*K] scratch */);
+
+/* ------------------------------------------------------------------------------------------
+ * Pixel-wise losses on logits (fp32 NHWC [N,H,W,C], C <= 32)
+ * softmax_kl : ref whl:deepclustering2/loss/kl_losses.py:107-126 on softmax(logits)
+ *              (semi_seg/epocher.py:165-166) with the one-hot of class2one_hot
+ *              (whl:deepclustering2/utils/general.py:221-235) taken from int64 labels [N,H,W]:
+ *              loss = mean_{n,h,w} sum_c -t*log((p+1e-16)/(t+1e-16)); glogits = upstream * d/dlogits.
+ *              A label outside [0,C) sets *bad_label (int32) != 0 (the reference asserts).
+ * softmax_mse: ref semi_seg/epocher.py:221-224 -- mean((softmax(a) - softmax(flip(b)))^2) over all
+ *              elements, b detached; flip(b) per `flips` is index math.  ga = upstream * d/da.
+ * `upstream` = fp32 device scalar (may be NULL = 1.0).  Results are deterministic (two-pass sums).
+ * ------------------------------------------------------------------------------------------ */
+int64_t miseg_loss_ws_bytes(int64_t N, int64_t H, int64_t W);
+int miseg_softmax_kl(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
+                     int64_t C, const float* upstream, float* loss, float* glogits, int32_t* bad_label, void* ws,
+                     int64_t ws_bytes);
+int miseg_softmax_mse(void* stream, const float* a, const float* b, const int32_t* flips, int64_t N, int64_t H,
+                      int64_t W, int64_t C, const float* upstream, float* loss, float* ga, void* ws,
+                      int64_t ws_bytes);
+/* per-sample H/W flip of an [N,C,H,W]-indexed tensor with arbitrary element strides (in elements),
+ * elem_bytes in {2,4,8}; ref whl:deepclustering2/augment/tensor_augment.py:31-39. Bit-exact. */
+int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
+               const int64_t* in_strides4, const int64_t* out_strides4, int elem_bytes, const int32_t* flips);
+/* argmax over channels + per-sample per-class intersection/union counts (int64 [N][C] each);
+ * ref semi_seg/epocher.py:183 + whl:.../general_dice_meter.py:141-172. pred (int64 [N,H,W]) optional. */
+int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
+                      int64_t C, int64_t* pred, int64_t* inter, int64_t* uni);
+
+/* ------------------------------------------------------------------------------------------
+ * U-Net building blocks   ref: contrastyou/arch/unet.py:10-40, 86-133
+ * Weights arrive in the reference's OIHW fp32 layout and are re-packed per call into the
+ * operand layout [tap][n][k] of type dt (pack kinds: 0 = forward: n = Cout, k = Cin; 1 = dgrad: taps
+ * mirrored, n = input channels [ci_begin, ci_begin+ci_count) -- one slice per concat source -- k = Cout).
+ * The 1-channel stem (unet.py:66) runs through the same kernels with its input zero-padded to one
+ * 16-byte channel vector (miseg_cast_pad) and its weight padded likewise by the host.
+ * conv3x3: stride 1, pad 1, no bias (unet.py:15,18,33).  Input = channel-concat of up to two
+ * NHWC sources (torch.cat((skip, up),1), unet.py:109-125), each optionally read through a
+ * nearest x2 upsample (nn.Upsample(scale_factor=2), unet.py:32): src s has C{s} channels and
+ * spatial size (H>>ups{s}, W>>ups{s}).
+ *   fwd   : out NHWC [N,H,W,Cout] (dt) = raw conv; if stats != NULL also writes per-block
+ *           partial (sum, sumsq) of the fp32 accumulators for BatchNorm (see bn_finalize).
+ *   dgrad : is conv3x3_fwd on grad_out with pack kind 1, Cin<->Cout.
+ *   wgrad : gw OIHW fp32 [Cout][C0+C1][3][3] (overwritten), deterministic split-K.
+ * ------------------------------------------------------------------------------------------ */
+int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w_oihw, int64_t Cout, int64_t Cin, int kind,
+                               int64_t ci_begin, int64_t ci_count, void* packed);
+/* number of per-block (sum, sumsq) partial rows conv3x3_fwd writes: stats_partials = fp32[parts][2][Cout] */
+int64_t miseg_conv3x3_stats_parts(int64_t N, int64_t H, int64_t W);
+int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
+                      int ups1, int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out,
+                      float* stats_partials);
+int64_t miseg_conv3x3_wgrad_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
+                        int ups1, int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw_oihw,
+                        void* ws, int64_t ws_bytes);
+
+/* BatchNorm2d (training: batch statistics; eval: running statistics) + ReLU
+ * ref: unet.py:16-17,19-20,34-35 (nn.BatchNorm2d defaults eps=1e-5, momentum=0.1).
+ * bn_finalize   : partials -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale
+ *                 (saved[4][C]); updates running_mean/var (unbiased var) and
+ *                 num_batches_tracked (int64 device scalar) when running_mean != NULL.
+ * bn_eval_coeffs: saved[2..3] from running stats.
+ * bn_relu_fwd   : y = relu(raw*scale+shift), NHWC dt, optional fused 2x2 max-pool second
+ *                 output (nn.MaxPool2d(2,2), unet.py:61-64) when pooled != NULL.
+ * bn_relu_bwd   : gy (+ optional gpool routed to the first arg-max of each 2x2 window, torch
+ *                 semantics) -> graw (dt), ggamma, gbeta.  Two passes (reduce, apply).
+ * ------------------------------------------------------------------------------------------ */
+int miseg_bn_finalize(void* stream, const float* stats_partials, int64_t nparts, int64_t C, int64_t count,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, float* saved);
+int miseg_bn_eval_coeffs(void* stream, int64_t C, const float* gamma, const float* beta, float eps,
+                         const float* running_mean, const float* running_var, float* saved);
+int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C,
+                      const float* saved, void* y, void* pooled);
+int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t C);
+int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool,
+                      int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
+                      int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes);
+/* backward of nearest x2 upsample: out[n,h,w,c] = sum of the 2x2 block of in (NHWC dt). */
+int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out,
+                     int accumulate);
+/* dt tensor elementwise: dst += src (skip-connection gradient joins). */
+int miseg_axpy(void* stream, int dt, const void* src, void* dst, int64_t numel);
+/* fp32 image [npix][Cin] -> dt [npix][CP], channels >= Cin zero-filled (stem input, CP = one 16-byte vector). */
+int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64_t Cin, int dt_out, void* out, int64_t CP);
+
+/* the 1x1 logits head with bias (unet.py:84,129): in NHWC dt [N,H,W,16] -> logits fp32 NHWC [N,H,W,Cout]. */
+int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                      const float* w, const float* bias, int64_t Cout, float* out);
+int64_t miseg_conv1x1_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, int64_t N, int64_t H, int64_t W,
+                      int64_t Cin, const float* w, int64_t Cout, void* gin, float* gw, float* gbias, void* ws,
+                      int64_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam with L2 weight decay on one flat fp32 buffer   ref: semi_seg/trainer.py:67-72,179-184
+ * (torch.optim.Adam semantics).  step/lr live on the host; bias corrections are computed on the
+ * host in double and passed in, so the launch is graph-capturable with scalars in `hyper`
+ * (fp32[4] device: lr/bc1, 1/sqrt(bc2), eps, weight_decay) refreshed by a tiny memcpy.
+ * ------------------------------------------------------------------------------------------ */
+int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    int64_t numel, float beta1, float beta2, const float* hyper);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISEG_HIP_H */

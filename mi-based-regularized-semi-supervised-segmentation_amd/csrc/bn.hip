@@ -1,0 +1,441 @@
+// BatchNorm2d(train/eval) + ReLU (+ fused 2x2 max-pool), their backward, and the small NHWC data
+// movers (upsample backward, gradient joins, casts) plus fused Adam.
+// ref: contrastyou/arch/unet.py:16-17,19-20,34-35 (BN+ReLU), :61-64 (MaxPool2d(2,2)), :32 (Upsample x2);
+//      optimiser: semi_seg/trainer.py:67-72,179-184 (torch.optim.Adam with L2 weight decay).
+// All HBM-bound: 16-byte vectors per thread, grid-stride, deterministic two-pass channel sums.
+#include "common.h"
+
+namespace miseg {
+
+template <typename T> struct VT;
+template <> struct VT<float> {
+    static constexpr int V = 4;
+    typedef float4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+    static __device__ __forceinline__ Raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct VT<bf16> {
+    static constexpr int V = 8;
+    typedef uint4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+        const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ Raw pack(const float* f) {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+        return make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+// ---- statistics -> coefficients.  saved = [mean | invstd | scale | shift] (4*C floats)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          long long* __restrict__ nbt, float* __restrict__ saved) {
+    __shared__ float red[17];
+    const int c = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = threadIdx.x; q < nparts; q += 256) {
+        s1 += parts[((size_t)q * 2 + 0) * C + c];
+        s2 += parts[((size_t)q * 2 + 1) * C + c];
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        const float mean = s1 / count;
+        float var = s2 / count - mean * mean;  // biased batch variance
+        var = fmaxf(var, 0.f);
+        const float invstd = rsqrtf(var + eps);
+        const float sc = gamma[c] * invstd;
+        saved[c] = mean; saved[C + c] = invstd; saved[2 * C + c] = sc; saved[3 * C + c] = beta[c] - mean * sc;
+        if (rmean) {
+            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+            if (c == 0 && nbt) nbt[0] += 1;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ saved) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float invstd = rsqrtf(rvar[c] + eps), sc = gamma[c] * invstd;
+        saved[c] = rmean[c]; saved[C + c] = invstd; saved[2 * C + c] = sc; saved[3 * C + c] = beta[c] - rmean[c] * sc;
+    }
+}
+
+// ---- y = relu(raw*scale+shift); optional 2x2 max-pool of y (one thread = one 2x2 window x V channels)
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ raw, int N, int H, int W, int C,
+                                                          const float* __restrict__ saved, T* __restrict__ y, T* __restrict__ pooled) {
+    constexpr int V = VT<T>::V;
+    typedef typename VT<T>::Raw Raw;
+    const int CV = C / V;
+    const float* scale = saved + 2 * C;
+    const float* shift = saved + 3 * C;
+    if (!POOL) {
+        const int64_t total = (int64_t)N * H * W * CV;
+        for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int cv = e % CV;
+            float f[V];
+            VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[e], f);
+#pragma unroll
+            for (int i = 0; i < V; ++i) f[i] = fmaxf(f[i] * scale[cv * V + i] + shift[cv * V + i], 0.f);
+            reinterpret_cast<Raw*>(y)[e] = VT<T>::pack(f);
+        }
+    } else {
+        const int Hp = H / 2, Wp = W / 2;
+        const int64_t total = (int64_t)N * Hp * Wp * CV;
+        for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int cv = e % CV, wp = (e / CV) % Wp, hp = (e / ((int64_t)CV * Wp)) % Hp, n = e / ((int64_t)CV * Wp * Hp);
+            float mx[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) mx[i] = -3.4e38f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t o = ((((int64_t)n * H + 2 * hp + (q >> 1)) * W + 2 * wp + (q & 1)) * CV + cv);
+                float f[V];
+                VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[o], f);
+#pragma unroll
+                for (int i = 0; i < V; ++i) { f[i] = fmaxf(f[i] * scale[cv * V + i] + shift[cv * V + i], 0.f); }
+                // the max is taken on the values as STORED (rounded to T), like torch pooling the bf16 tensor
+                Raw pk = VT<T>::pack(f);
+                reinterpret_cast<Raw*>(y)[o] = pk;
+                VT<T>::unpack(pk, f);
+#pragma unroll
+                for (int i = 0; i < V; ++i) mx[i] = fmaxf(mx[i], f[i]);
+            }
+            reinterpret_cast<Raw*>(pooled)[e] = VT<T>::pack(mx);
+        }
+    }
+}
+
+// ---- backward pass 1: dz = (gy [+ routed gpool]) * (y > 0); writes dz into graw, per-block channel sums of
+//      dz and dz*xhat.  One thread = one 2x2 window x V channels (H, W even when gpool != NULL; any size otherwise
+//      via the 1x1 "window" path).
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ raw, const T* __restrict__ y, const T* __restrict__ gy,
+                                                                 const T* __restrict__ gpool, int N, int H, int W, int C,
+                                                                 const float* __restrict__ saved, T* __restrict__ graw,
+                                                                 float* __restrict__ parts) {
+    constexpr int V = VT<T>::V;
+    typedef typename VT<T>::Raw Raw;
+    extern __shared__ float sacc[];  // [256][2*V] transposed reduce
+    const int CV = C / V;
+    const float* mean = saved;
+    const float* invstd = saved + C;
+    // threads are assigned a fixed channel vector: stride over pixels with step (total threads / CV)
+    const int tpb = 256, lanesPerPix = CV;  // requires (gridDim.x*256) % CV == 0 (host guarantees CV | 256)
+    const int64_t gthreads = (int64_t)gridDim.x * tpb;
+    const int64_t gid = blockIdx.x * (int64_t)tpb + threadIdx.x;
+    const int cv = gid % lanesPerPix;
+    float a1[V], a2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) a1[i] = a2[i] = 0.f;
+    if (!POOL) {
+        const int64_t npix = (int64_t)N * H * W;
+        for (int64_t px = gid / lanesPerPix; px < npix; px += gthreads / lanesPerPix) {
+            const int64_t o = px * CV + cv;
+            float fy[V], fg[V], fr[V];
+            VT<T>::unpack(reinterpret_cast<const Raw*>(y)[o], fy);
+            VT<T>::unpack(reinterpret_cast<const Raw*>(gy)[o], fg);
+            VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[o], fr);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float dz = fy[i] > 0.f ? fg[i] : 0.f;
+                fg[i] = dz;
+                a1[i] += dz;
+                a2[i] += dz * (fr[i] - mean[cv * V + i]) * invstd[cv * V + i];
+            }
+            reinterpret_cast<Raw*>(graw)[o] = VT<T>::pack(fg);
+        }
+    } else {
+        const int Hp = H / 2, Wp = W / 2;
+        const int64_t nwin = (int64_t)N * Hp * Wp;
+        for (int64_t wi = gid / lanesPerPix; wi < nwin; wi += gthreads / lanesPerPix) {
+            const int wp = wi % Wp, hp = (wi / Wp) % Hp, n = wi / ((int64_t)Wp * Hp);
+            float gp[V], ys[4][V], best[V];
+            int arg[V];
+            VT<T>::unpack(reinterpret_cast<const Raw*>(gpool)[wi * CV + cv], gp);
+            int64_t offs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                offs[q] = ((((int64_t)n * H + 2 * hp + (q >> 1)) * W + 2 * wp + (q & 1)) * CV + cv);
+                VT<T>::unpack(reinterpret_cast<const Raw*>(y)[offs[q]], ys[q]);
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                best[i] = ys[0][i]; arg[i] = 0;
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                    if (ys[q][i] > best[i]) { best[i] = ys[q][i]; arg[i] = q; }  // first max in scan order
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float fg[V], fr[V];
+                if (gy) VT<T>::unpack(reinterpret_cast<const Raw*>(gy)[offs[q]], fg);
+                else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) fg[i] = 0.f;
+                }
+                VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[offs[q]], fr);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float g = fg[i] + (arg[i] == q ? gp[i] : 0.f);
+                    const float dz = ys[q][i] > 0.f ? g : 0.f;
+                    fg[i] = dz;
+                    a1[i] += dz;
+                    a2[i] += dz * (fr[i] - mean[cv * V + i]) * invstd[cv * V + i];
+                }
+                reinterpret_cast<Raw*>(graw)[offs[q]] = VT<T>::pack(fg);
+            }
+        }
+    }
+    // block reduce over threads sharing cv (256 % CV == 0): sacc[tid][2V]
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sacc[threadIdx.x * 2 * V + i] = a1[i]; sacc[threadIdx.x * 2 * V + V + i] = a2[i]; }
+    __syncthreads();
+    if (threadIdx.x < CV) {
+        // block's first thread has gid % CV == (blockIdx.x*256) % CV == 0 since CV | 256
+        for (int i = 0; i < V; ++i) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int t = threadIdx.x; t < 256; t += CV) { s1 += sacc[t * 2 * V + i]; s2 += sacc[t * 2 * V + V + i]; }
+            parts[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x * V + i] = s1;
+            parts[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x * V + i] = s2;
+        }
+    }
+}
+
+// coeffs[3][C]: a = gamma*invstd, b = mean(dz), c = mean(dz*xhat) (training) or b = c = 0 (eval); also ggamma, gbeta
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ saved,
+                                                              int training, float* __restrict__ coeffs, float* __restrict__ ggamma,
+                                                              float* __restrict__ gbeta) {
+    __shared__ float red[17];
+    const int c = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = threadIdx.x; q < nparts; q += 256) {
+        s1 += parts[((size_t)q * 2 + 0) * C + c];
+        s2 += parts[((size_t)q * 2 + 1) * C + c];
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        gbeta[c] = s1;
+        ggamma[c] = s2;
+        coeffs[c] = gamma[c] * saved[C + c];
+        coeffs[C + c] = training ? s1 / count : 0.f;
+        coeffs[2 * C + c] = training ? s2 / count : 0.f;
+    }
+}
+
+// graw = a*(dz - b - xhat*c)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ raw, int64_t nvec, int C, const float* __restrict__ saved,
+                                                           const float* __restrict__ coeffs, T* __restrict__ graw) {
+    constexpr int V = VT<T>::V;
+    typedef typename VT<T>::Raw Raw;
+    const int CV = C / V;
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
+        const int cv = e % CV;
+        float fr[V], fd[V];
+        VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[e], fr);
+        VT<T>::unpack(reinterpret_cast<const Raw*>(graw)[e], fd);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = cv * V + i;
+            const float xhat = (fr[i] - saved[c]) * saved[C + c];
+            fd[i] = coeffs[c] * (fd[i] - coeffs[C + c] - xhat * coeffs[2 * C + c]);
+        }
+        reinterpret_cast<Raw*>(graw)[e] = VT<T>::pack(fd);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ in, int N, int H, int W, int C, T* __restrict__ out, int accumulate) {
+    constexpr int V = VT<T>::V;
+    typedef typename VT<T>::Raw Raw;
+    const int CV = C / V, Hp = H / 2, Wp = W / 2;
+    const int64_t total = (int64_t)N * Hp * Wp * CV;
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int cv = e % CV, wp = (e / CV) % Wp, hp = (e / ((int64_t)CV * Wp)) % Hp, n = e / ((int64_t)CV * Wp * Hp);
+        float s[V];
+        if (accumulate) VT<T>::unpack(reinterpret_cast<const Raw*>(out)[e], s);
+        else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) s[i] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float f[V];
+            VT<T>::unpack(reinterpret_cast<const Raw*>(in)[((((int64_t)n * H + 2 * hp + (q >> 1)) * W + 2 * wp + (q & 1)) * CV + cv)], f);
+#pragma unroll
+            for (int i = 0; i < V; ++i) s[i] += f[i];
+        }
+        reinterpret_cast<Raw*>(out)[e] = VT<T>::pack(s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t nvec) {
+    constexpr int V = VT<T>::V;
+    typedef typename VT<T>::Raw Raw;
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
+        float a[V], b[V];
+        VT<T>::unpack(reinterpret_cast<const Raw*>(src)[e], a);
+        VT<T>::unpack(reinterpret_cast<const Raw*>(dst)[e], b);
+#pragma unroll
+        for (int i = 0; i < V; ++i) b[i] += a[i];
+        reinterpret_cast<Raw*>(dst)[e] = VT<T>::pack(b);
+    }
+}
+
+// image [npix] (1 channel) -> [npix][CP] with channel 0 = value, rest 0 (stem input padded to a full vector)
+template <typename TI, typename TO>
+__global__ void cast_pad_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t npix, int Cin, int CP) {
+    const int64_t total = npix * CP;
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = e % CP;
+        out[e] = from_f32<TO>(c < Cin ? to_f32(in[(e / CP) * Cin + c]) : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float b1, float b2, const float* __restrict__ hyper) {
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2], wd = hyper[3];
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] + wd * p[i];
+        float mi = m[i] * b1 + (1.f - b1) * gi;
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+static inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 8192)); }
+static inline int red_blocks(int64_t npix, int CV) { (void)CV; return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(npix, 64), 1024)); }
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int miseg_bn_finalize(void* stream, const float* parts, int64_t nparts, int64_t C, int64_t count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* rmean, float* rvar, int64_t* nbt, float* saved) {
+    MISEG_REQUIRE(parts && gamma && beta && saved && C > 0 && nparts > 0 && count > 0, "bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), parts, (int)nparts, (int)C, (float)count, gamma,
+                       beta, eps, momentum, rmean, rvar, (long long*)nbt, saved);
+    MISEG_LAUNCH_CHECK("bn_finalize_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_bn_eval_coeffs(void* stream, int64_t C, const float* gamma, const float* beta, float eps, const float* rmean,
+                                    const float* rvar, float* saved) {
+    MISEG_REQUIRE(gamma && beta && rmean && rvar && saved && C > 0, "bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream), (int)C, gamma, beta, eps, rmean, rvar, saved);
+    MISEG_LAUNCH_CHECK("bn_eval_coeffs_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C, const float* saved,
+                                 void* y, void* pooled) {
+    MISEG_REQUIRE(raw && saved && y, "bn_relu_fwd: null pointer");
+    const int V = dt == MISEG_BF16 ? 8 : 4;
+    MISEG_REQUIRE(C % V == 0, "bn_relu_fwd: C must be a multiple of %d", V);
+    MISEG_REQUIRE(!pooled || (H % 2 == 0 && W % 2 == 0), "bn_relu_fwd: pooling needs even H, W");
+    hipStream_t st = as_stream(stream);
+    const int64_t total = pooled ? N * (H / 2) * (W / 2) * (C / V) : N * H * W * (C / V);
+    const int nb = ew_blocks(total);
+    if (dt == MISEG_F32) {
+        if (pooled) hipLaunchKernelGGL((bn_relu_fwd_kernel<float, true>), dim3(nb), dim3(256), 0, st, (const float*)raw, (int)N, (int)H, (int)W, (int)C, saved, (float*)y, (float*)pooled);
+        else hipLaunchKernelGGL((bn_relu_fwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, (const float*)raw, (int)N, (int)H, (int)W, (int)C, saved, (float*)y, (float*)nullptr);
+    } else if (dt == MISEG_BF16) {
+        if (pooled) hipLaunchKernelGGL((bn_relu_fwd_kernel<bf16, true>), dim3(nb), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)pooled);
+        else hipLaunchKernelGGL((bn_relu_fwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)nullptr);
+    } else return fail(MISEG_E_INVALID, "bn_relu_fwd: bad dtype");
+    MISEG_LAUNCH_CHECK("bn_relu_fwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t C) {
+    return ((int64_t)red_blocks(N * H * W, 1) * 2 * C + 3 * C) * 4;
+}
+
+extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
+                                 int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
+                                 float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(raw && y && (gy || gpool) && gamma && saved && graw && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
+    const int V = dt == MISEG_BF16 ? 8 : 4;
+    const int CV = (int)(C / V);
+    MISEG_REQUIRE(C % V == 0 && 256 % CV == 0, "bn_relu_bwd: C/%d must divide 256", V);
+    MISEG_REQUIRE(!gpool || (H % 2 == 0 && W % 2 == 0), "bn_relu_bwd: pooling needs even H, W");
+    MISEG_REQUIRE(ws_bytes >= miseg_bn_bwd_ws_bytes(N, H, W, C), "bn_relu_bwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int64_t npix = N * H * W;
+    const int nb = red_blocks(npix, CV);
+    float* parts = (float*)ws;
+    float* coeffs = parts + (size_t)nb * 2 * C;
+    const size_t lb = (size_t)256 * 2 * V * 4;
+#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)y, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, (TT*)graw, parts)
+    if (dt == MISEG_F32) { if (gpool) RED(float, true); else RED(float, false); }
+    else if (dt == MISEG_BF16) { if (gpool) RED(bf16, true); else RED(bf16, false); }
+    else return fail(MISEG_E_INVALID, "bn_relu_bwd: bad dtype");
+#undef RED
+    MISEG_LAUNCH_CHECK("bn_relu_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta);
+    MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    const int64_t nvec = npix * CV;
+    if (dt == MISEG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const float*)raw, nvec, (int)C, saved, coeffs, (float*)graw);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const bf16*)raw, nvec, (int)C, saved, coeffs, (bf16*)graw);
+    MISEG_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out, int accumulate) {
+    MISEG_REQUIRE(in && out && H % 2 == 0 && W % 2 == 0, "sumpool2x2: bad args");
+    const int V = dt == MISEG_BF16 ? 8 : 4;
+    MISEG_REQUIRE(C % V == 0, "sumpool2x2: C must be a multiple of %d", V);
+    const int64_t total = N * (H / 2) * (W / 2) * (C / V);
+    hipStream_t st = as_stream(stream);
+    if (dt == MISEG_F32) hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)in, (int)N, (int)H, (int)W, (int)C, (float*)out, accumulate);
+    else if (dt == MISEG_BF16) hipLaunchKernelGGL(sumpool2x2_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16*)in, (int)N, (int)H, (int)W, (int)C, (bf16*)out, accumulate);
+    else return fail(MISEG_E_INVALID, "sumpool2x2: bad dtype");
+    MISEG_LAUNCH_CHECK("sumpool2x2_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_axpy(void* stream, int dt, const void* src, void* dst, int64_t numel) {
+    MISEG_REQUIRE(src && dst, "axpy: null pointer");
+    const int V = dt == MISEG_BF16 ? 8 : 4;
+    MISEG_REQUIRE(numel % V == 0, "axpy: numel must be a multiple of %d", V);
+    hipStream_t st = as_stream(stream);
+    if (dt == MISEG_F32) hipLaunchKernelGGL(axpy_kernel<float>, dim3(ew_blocks(numel / V)), dim3(256), 0, st, (const float*)src, (float*)dst, numel / V);
+    else if (dt == MISEG_BF16) hipLaunchKernelGGL(axpy_kernel<bf16>, dim3(ew_blocks(numel / V)), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, numel / V);
+    else return fail(MISEG_E_INVALID, "axpy: bad dtype");
+    MISEG_LAUNCH_CHECK("axpy_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64_t Cin, int dt_out, void* out, int64_t CP) {
+    MISEG_REQUIRE(in && out && Cin > 0 && CP >= Cin, "cast_pad: bad args");
+    hipStream_t st = as_stream(stream);
+    const int nb = ew_blocks(npix * CP);
+    if (dt_out == MISEG_F32) hipLaunchKernelGGL((cast_pad_kernel<float, float>), dim3(nb), dim3(256), 0, st, in, (float*)out, npix, (int)Cin, (int)CP);
+    else if (dt_out == MISEG_BF16) hipLaunchKernelGGL((cast_pad_kernel<float, bf16>), dim3(nb), dim3(256), 0, st, in, (bf16*)out, npix, (int)Cin, (int)CP);
+    else return fail(MISEG_E_INVALID, "cast_pad: bad dtype");
+    MISEG_LAUNCH_CHECK("cast_pad_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                               float beta1, float beta2, const float* hyper) {
+    MISEG_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && numel > 0, "adam_step: bad args");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(numel)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper);
+    MISEG_LAUNCH_CHECK("adam_kernel");
+    return MISEG_OK;
+}

@@ -1,0 +1,95 @@
+// Shared helpers for the gfx950 kernels behind include/miseg_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+#include "../../include/miseg_hip.h"
+
+namespace miseg {
+
+// ---- error plumbing (thread-local message, C return codes) -------------------------------
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+
+#define MISEG_REQUIRE(cond, ...)                                  \
+    do {                                                          \
+        if (!(cond)) return ::miseg::fail(MISEG_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define MISEG_LAUNCH_CHECK(what)                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess) return ::miseg::fail(MISEG_E_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- element types ------------------------------------------------------------------------
+typedef __hip_bfloat16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
+    bf16 h = __float2bfloat16(v);
+    return *reinterpret_cast<unsigned short*>(&h);
+}
+
+// ---- wave64 / block reductions --------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Sum over a block of up to 1024 threads; result valid in every thread.  `red` = >=17 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += red[i];  // fixed order: deterministic
+        red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
+}
+__device__ __forceinline__ float block_min(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_min(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+        for (int i = 1; i < nw; ++i) t = fminf(t, red[i]);
+        red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+// Flip-aware source coordinate: bit0 = flip H, bit1 = flip W.
+__device__ __forceinline__ int flip_h(int h, int H, int f) { return (f & 1) ? (H - 1 - h) : h; }
+__device__ __forceinline__ int flip_w(int w, int W, int f) { return (f & 2) ? (W - 1 - w) : w; }
+
+}  // namespace miseg

@@ -1,0 +1,490 @@
+// U-Net convolutions on gfx950 MFMA (ref: contrastyou/arch/unet.py:10-40, 66-84, 86-133).
+//
+// conv3x3 (stride 1, pad 1, no bias) as an implicit GEMM over NHWC activations:
+//   M = 16-pixel row segments, N = output channels, reduction = 9 taps x input channels.
+// The A operand is gathered straight from a haloed LDS tile of the input (a tap shift is a whole
+// pixel = a whole channel vector, so fragments stay 16-byte aligned); nearest-x2 upsampling and
+// the skip-connection concat are index math in the tile loader, never materialised.
+// dt = bf16: v_mfma_f32_16x16x32_bf16; dt = f32: v_mfma_f32_16x16x4_f32 (exact fp32 parity mode).
+// Weight gradients use the fp32 MFMA for both dtypes (deterministic split-K over pixels).
+#include "common.h"
+
+namespace miseg {
+
+constexpr int kCT = 256;  // threads per block (4 waves)
+constexpr int TH = 16;    // tile rows: 4 per wave
+constexpr int CK = 32;    // input channels per LDS chunk
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int CKP = 40;   // padded channel stride (elements): 80 B rows, 16-B aligned, conflict-free b128
+    static constexpr int VEC = 8;    // elements per 16-byte vector
+    typedef s16x8 Frag;
+    static __device__ __forceinline__ Frag load(const bf16* base, int kq) { return *reinterpret_cast<const Frag*>(base + 8 * kq); }
+    static __device__ __forceinline__ void mma_chunk(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int CKP = 34;   // 2m+kq bank pattern: conflict-free ds_read_b32 gathers
+    static constexpr int VEC = 4;
+    struct Frag { float v[8]; };
+    static __device__ __forceinline__ Frag load(const float* base, int kq) {
+        Frag f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) f.v[s] = base[4 * s + kq];
+        return f;
+    }
+    static __device__ __forceinline__ void mma_chunk(const Frag& a, const Frag& b, f32x4& c) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], c, 0, 0, 0);
+    }
+};
+
+struct ConvSrc {
+    const void* p0; const void* p1;
+    int C0, C1, ups0, ups1;
+};
+
+template <typename T>
+__device__ __forceinline__ void zero_vec(T* dst) {
+#pragma unroll
+    for (int i = 0; i < Mma<T>::VEC; ++i) dst[i] = from_f32<T>(0.f);
+}
+
+// COT: output channels per block; TW: tile width (32 or 16).  grid = (N*tilesR*tilesC, ceil(Cout/COT)).
+template <typename T, int COT, int TW>
+__global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
+                                                        T* __restrict__ out, float* __restrict__ stats) {
+    typedef Mma<T> MM;
+    constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
+    constexpr int IW = TW + 2, IH = TH + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][CKP]
+    T* Ws = Is + IH * IW * CKP;                            // [9][COT][CKP]
+    const int Cin = src.C0 + src.C1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int tilesC = (W + TW - 1) / TW, tilesR = (H + TH - 1) / TH;
+    const int tc = blockIdx.x % tilesC, tr = (blockIdx.x / tilesC) % tilesR, n = blockIdx.x / (tilesC * tilesR);
+    const int h0 = tr * TH, w0 = tc * TW, co0 = blockIdx.y * COT;
+
+    f32x4 acc[MTW][NT];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();
+        // ---- input tile (halo 1), VEC channels per thread-iteration
+        for (int idx = tid; idx < IH * IW * (CK / VEC); idx += kCT) {
+            const int v = idx % (CK / VEC), px = idx / (CK / VEC), ix = px % IW, iy = px / IW;
+            const int h = h0 - 1 + iy, w = w0 - 1 + ix, c = c0 + v * VEC;
+            T* dst = Is + (iy * IW + ix) * CKP + v * VEC;
+            if (h < 0 || h >= H || w < 0 || w >= W || c >= Cin) { zero_vec<T>(dst); continue; }
+            const T* sp;
+            if (c < src.C0) {
+                const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
+            } else {
+                const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
+            }
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sp);
+        }
+        // ---- weight chunk: packed [tap][Cout][Cin]
+        for (int idx = tid; idx < 9 * COT * (CK / VEC); idx += kCT) {
+            const int v = idx % (CK / VEC), co = (idx / (CK / VEC)) % COT, tap = idx / ((CK / VEC) * COT);
+            const int c = c0 + v * VEC;
+            T* dst = Ws + (tap * COT + co) * CKP + v * VEC;
+            if (co0 + co >= Cout || c >= Cin) { zero_vec<T>(dst); continue; }
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            typename MM::Frag bf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[t] = MM::load(Ws + (tap * COT + t * 16 + l15) * CKP, kq);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int row = wv * 4 + m / MTR + ky, col = (m % MTR) * 16 + l15 + kx;
+                typename MM::Frag af = MM::load(Is + (row * IW + col) * CKP, kq);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) MM::mma_chunk(af, bf[t], acc[m][t]);
+            }
+        }
+    }
+    // ---- epilogue: D[row = pixel kq*4+r][col = co l15]
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int h = h0 + wv * 4 + m / MTR;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int w = w0 + (m % MTR) * 16 + kq * 4 + r;
+            const bool ok = h < H && w < W;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co0 + t * 16 + l15;
+                const float v = acc[m][t][r];
+                if (ok && co < Cout) {
+                    out[(((size_t)n * H + h) * W + w) * Cout + co] = from_f32<T>(v);
+                    s1[t] += v;
+                    s2[t] += v * v;
+                }
+            }
+        }
+    }
+    if (stats) {
+        __shared__ float sred[4][2][COT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float a = s1[t], b = s2[t];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (kq == 0) { sred[wv][0][t * 16 + l15] = a; sred[wv][1][t * 16 + l15] = b; }
+        }
+        __syncthreads();
+        if (tid < COT && co0 + tid < Cout) {
+            float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
+            float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+            stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
+            stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
+        }
+    }
+}
+
+// OIHW fp32 -> packed [tap][n][k] of T.  kind 0 (forward): n = o, k = i, tap = ky*3+kx.
+// kind 1 (dgrad): n = i - ci_begin (ci_count of them), k = o, tap mirrored (2-ky, 2-kx).
+template <typename T>
+__global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int kind, int ci_begin, int ci_count, T* __restrict__ pk) {
+    const int Nn = kind ? ci_count : Cout, Kk = kind ? Cout : Cin;
+    const int total = 9 * Nn * Kk;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k = e % Kk, nn = (e / Kk) % Nn, tap = e / (Kk * Nn);
+        const int ky = tap / 3, kx = tap % 3;
+        float v;
+        if (!kind) v = w[(((size_t)nn * Cin + k) * 3 + ky) * 3 + kx];
+        else v = w[(((size_t)k * Cin + ci_begin + nn) * 3 + (2 - ky)) * 3 + (2 - kx)];
+        pk[e] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// gw[co][ci][ky][kx] = sum_{n,h,w} gout[n,h,w,co] * in[n,h+ky-1,w+kx-1,ci]   (fp32 MFMA, split over pixels)
+// block = (co tile 32, ci chunk 32, split); wave = 2 of the tile's 8 rows; acc 2 x 18 tiles.
+constexpr int WG_TH = 8, WG_TW = 32, WG_P = 34;  // tile rows / cols, LDS channel stride (32 + 2)
+
+template <typename T>
+__global__ __launch_bounds__(kCT, 1) void conv3x3_wgrad_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ gout, int Cout,
+                                                              int nsplit, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* Gs = wsm;                                   // [WG_TH*WG_TW][WG_P]
+    float* Is = wsm + WG_TH * WG_TW * WG_P;            // [(WG_TH+2)*(WG_TW+2)][WG_P]
+    const int Cin = src.C0 + src.C1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const int tilesC = (W + WG_TW - 1) / WG_TW, tilesR = (H + WG_TH - 1) / WG_TH;
+    const int ntiles = N * tilesR * tilesC;
+    constexpr int IW = WG_TW + 2;
+    f32x4 acc[2][18];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 18; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+        __syncthreads();
+        for (int idx = tid; idx < WG_TH * WG_TW * 32; idx += kCT) {
+            const int c = idx & 31, px = idx >> 5, ix = px % WG_TW, iy = px / WG_TW;
+            const int h = h0 + iy, w = w0 + ix;
+            float v = 0.f;
+            if (h < H && w < W && co0 + c < Cout) v = to_f32(gout[(((size_t)n * H + h) * W + w) * Cout + co0 + c]);
+            Gs[px * WG_P + c] = v;
+        }
+        for (int idx = tid; idx < (WG_TH + 2) * IW * 32; idx += kCT) {
+            const int c = idx & 31, px = idx >> 5, ix = px % IW, iy = px / IW;
+            const int h = h0 - 1 + iy, w = w0 - 1 + ix, cc = ci0 + c;
+            float v = 0.f;
+            if (h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
+                if (cc < src.C0) {
+                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                    v = to_f32(reinterpret_cast<const T*>(src.p0)[(((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + cc]);
+                } else {
+                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                    v = to_f32(reinterpret_cast<const T*>(src.p1)[(((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + cc - src.C0]);
+                }
+            }
+            Is[px * WG_P + c] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wv * 2 + rr;
+#pragma unroll 1
+            for (int cs = 0; cs < WG_TW; cs += 4) {
+                const float a0 = Gs[(row * WG_TW + cs + kq) * WG_P + l15];
+                const float a1 = Gs[(row * WG_TW + cs + kq) * WG_P + 16 + l15];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    const float* ip = Is + ((row + ky) * IW + cs + kq + kx) * WG_P + l15;
+                    const float b0 = ip[0], b1 = ip[16];
+                    acc[0][tap * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][tap * 2 + 0], 0, 0, 0);
+                    acc[0][tap * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][tap * 2 + 1], 0, 0, 0);
+                    acc[1][tap * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][tap * 2 + 0], 0, 0, 0);
+                    acc[1][tap * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][tap * 2 + 1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // reduce the 4 waves in LDS (fixed order), write partial [split][co 32][tap 9][ci 32]
+    float* Ds = wsm;  // 32 x 288 floats
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 18; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = a * 16 + kq * 4 + r, col = (b / 2) * 32 + (b % 2) * 16 + l15;
+                        if (w == 0) Ds[co * 288 + col] = acc[a][b][r];
+                        else Ds[co * 288 + col] += acc[a][b][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* outp = partials + (((size_t)split * gridDim.z + blockIdx.z) * gridDim.y + blockIdx.y) * (32 * 288);
+    for (int e = tid; e < 32 * 288; e += kCT) outp[e] = Ds[e];
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int Cout, int Cin, int nco, int nci, float* __restrict__ gw) {
+    const int total = Cout * Cin * 9;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e % 9, ci = (e / 9) % Cin, co = e / (9 * Cin);
+        const int bz = co / 32, by = ci / 32;
+        const size_t off = ((size_t)bz * nci + by) * (32 * 288) + (co % 32) * 288 + tap * 32 + (ci % 32);
+        float s = 0.f;
+        for (int q = 0; q < nsplit; ++q) s += partials[(size_t)q * nco * nci * (32 * 288) + off];
+        gw[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 1x1 logits head
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ in, int64_t npix, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        float f[CI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) f[c] = to_f32(in[i * CI + c]);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float a = bias[o];
+#pragma unroll
+            for (int c = 0; c < CI; ++c) a += w[o * CI + c] * f[c];
+            out[i * CO + o] = a;
+        }
+    }
+}
+
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ in, const float* __restrict__ gout, int64_t npix,
+                                                          const float* __restrict__ w, T* __restrict__ gin, float* __restrict__ partials) {
+    __shared__ float red[4][CO * CI + CO];
+    float gwacc[CO * CI], gbacc[CO];
+#pragma unroll
+    for (int e = 0; e < CO * CI; ++e) gwacc[e] = 0.f;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) gbacc[o] = 0.f;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        float f[CI], g[CO];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) f[c] = to_f32(in[i * CI + c]);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) { g[o] = gout[i * CO + o]; gbacc[o] += g[o]; }
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) { a += w[o * CI + c] * g[o]; gwacc[o * CI + c] += g[o] * f[c]; }
+            if (gin) gin[i * CI + c] = from_f32<T>(a);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < CO * CI; ++e) {
+        float v = wave_sum(gwacc[e]);
+        if (lane == 0) red[wv][e] = v;
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        float v = wave_sum(gbacc[o]);
+        if (lane == 0) red[wv][CO * CI + o] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CO * CI + CO; e += 256)
+        partials[(size_t)blockIdx.x * (CO * CI + CO) + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+}
+
+__global__ void sum_parts2_kernel(const float* __restrict__ partials, int nparts, int len, int lenA, float* __restrict__ outA,
+                                  float* __restrict__ outB) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < nparts; ++q) s += partials[(size_t)q * len + e];
+        if (e < lenA) outA[e] = s; else outB[e - lenA] = s;
+    }
+}
+
+static inline int tile_w(int64_t W) { return W >= 32 ? 32 : 16; }
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, int64_t Cout, int64_t Cin, int kind, int64_t ci_begin,
+                                          int64_t ci_count, void* packed) {
+    MISEG_REQUIRE(w && packed && Cout > 0 && Cin > 0, "pack_conv3x3_weights: bad args");
+    if (!kind) { ci_begin = 0; ci_count = Cin; }
+    MISEG_REQUIRE(ci_begin >= 0 && ci_count > 0 && ci_begin + ci_count <= Cin, "pack_conv3x3_weights: bad channel slice");
+    const int total = (int)(9 * (kind ? ci_count * Cout : Cout * Cin));
+    const int nb = std::min((total + 255) / 256, 1024);
+    if (dt == MISEG_F32)
+        hipLaunchKernelGGL(pack_w_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), w, (int)Cout, (int)Cin, kind, (int)ci_begin, (int)ci_count, (float*)packed);
+    else if (dt == MISEG_BF16)
+        hipLaunchKernelGGL(pack_w_kernel<bf16>, dim3(nb), dim3(256), 0, as_stream(stream), w, (int)Cout, (int)Cin, kind, (int)ci_begin, (int)ci_count, (bf16*)packed);
+    else return fail(MISEG_E_INVALID, "pack_conv3x3_weights: bad dtype");
+    MISEG_LAUNCH_CHECK("pack_w_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int64_t miseg_conv3x3_stats_parts(int64_t N, int64_t H, int64_t W) {
+    const int tw = tile_w(W);
+    return N * cdiv(H, TH) * cdiv(W, tw);
+}
+
+extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                 int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats) {
+    MISEG_REQUIRE(in0 && packed_w && out, "conv3x3_fwd: null pointer");
+    MISEG_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0, "conv3x3_fwd: bad shape");
+    MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_fwd: second source missing");
+    MISEG_REQUIRE((ups0 == 0 || ups0 == 1) && (ups1 == 0 || ups1 == 1), "conv3x3_fwd: ups must be 0/1");
+    MISEG_REQUIRE((!ups0 || (H % 2 == 0 && W % 2 == 0)) && (!ups1 || (H % 2 == 0 && W % 2 == 0)), "conv3x3_fwd: upsampled size must be even");
+    const int vec = dt == MISEG_BF16 ? 8 : 4;
+    MISEG_REQUIRE(C0 % vec == 0 && C1 % vec == 0, "conv3x3_fwd: channel counts must be multiples of %d (use conv_small for the stem)", vec);
+    ConvSrc s{in0, in1, (int)C0, (int)C1, ups0, ups1};
+    const int tw = tile_w(W);
+    const unsigned gx = (unsigned)(N * cdiv(H, TH) * cdiv(W, tw));
+    hipStream_t st = as_stream(stream);
+#define LAUNCH(TT, COT, TWW)                                                                                              \
+    {                                                                                                                     \
+        size_t lb = ((size_t)(TH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::CKP * sizeof(TT);                                  \
+        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
+                           (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats);                                       \
+    }
+    if (dt == MISEG_BF16) {
+        if (Cout <= 16) { if (tw == 32) LAUNCH(bf16, 16, 32) else LAUNCH(bf16, 16, 16) }
+        else if (Cout <= 32) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
+        else { if (tw == 32) LAUNCH(bf16, 64, 32) else LAUNCH(bf16, 64, 16) }
+    } else if (dt == MISEG_F32) {
+        if (Cout <= 16) { if (tw == 32) LAUNCH(float, 16, 32) else LAUNCH(float, 16, 16) }
+        else { if (tw == 32) LAUNCH(float, 32, 32) else LAUNCH(float, 32, 16) }
+    } else return fail(MISEG_E_INVALID, "conv3x3_fwd: bad dtype");
+#undef LAUNCH
+    MISEG_LAUNCH_CHECK("conv3x3_kernel");
+    return MISEG_OK;
+}
+
+static int wgrad_splits(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+    const int64_t ntiles = N * cdiv(H, WG_TH) * cdiv(W, WG_TW);
+    const int64_t per = cdiv(Cin, 32) * cdiv(Cout, 32);
+    int64_t s = std::max<int64_t>(1, 512 / per);
+    return (int)std::min<int64_t>(s, ntiles);
+}
+
+extern "C" int64_t miseg_conv3x3_wgrad_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+    return (int64_t)wgrad_splits(N, H, W, Cin, Cout) * cdiv(Cin, 32) * cdiv(Cout, 32) * 32 * 288 * 4;
+}
+
+extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                   int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(in0 && gout && gw && ws, "conv3x3_wgrad: null pointer");
+    MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_wgrad: second source missing");
+    const int64_t Cin = C0 + C1;
+    MISEG_REQUIRE(ws_bytes >= miseg_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout), "conv3x3_wgrad: workspace too small");
+    ConvSrc s{in0, in1, (int)C0, (int)C1, ups0, ups1};
+    const int ns = wgrad_splits(N, H, W, Cin, Cout), nci = (int)cdiv(Cin, 32), nco = (int)cdiv(Cout, 32);
+    const size_t lb = ((size_t)WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * WG_P * 4;
+    hipStream_t st = as_stream(stream);
+    dim3 grid(ns, nci, nco);
+    if (dt == MISEG_F32) {
+        hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<float>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws);
+    } else if (dt == MISEG_BF16) {
+        hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<bf16>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
+    } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
+    MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
+    const int total = (int)(Cout * Cin * 9);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
+    MISEG_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t Cin, const float* w,
+                                 const float* bias, int64_t Cout, float* out) {
+    MISEG_REQUIRE(in && w && bias && out, "conv1x1_fwd: null pointer");
+    MISEG_REQUIRE(Cin == 16, "conv1x1_fwd: Cin must be 16 (unet.py:84)");
+    const int64_t npix = N * H * W;
+    const int nb = (int)std::min<int64_t>(cdiv(npix, 256), 4096);
+    hipStream_t st = as_stream(stream);
+#define L(CO)                                                                                                                      \
+    if (dt == MISEG_F32) hipLaunchKernelGGL((conv1x1_fwd_kernel<float, 16, CO>), dim3(nb), dim3(256), 0, st, (const float*)in, npix, w, bias, out); \
+    else hipLaunchKernelGGL((conv1x1_fwd_kernel<bf16, 16, CO>), dim3(nb), dim3(256), 0, st, (const bf16*)in, npix, w, bias, out)
+    switch (Cout) {
+        case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break;
+        case 5: L(5); break; case 8: L(8); break;
+        default: return fail(MISEG_E_INVALID, "conv1x1_fwd: unsupported Cout %ld", (long)Cout);
+    }
+#undef L
+    MISEG_LAUNCH_CHECK("conv1x1_fwd_kernel");
+    return MISEG_OK;
+}
+
+static int c1_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv(npix, 256), 1024); }
+extern "C" int64_t miseg_conv1x1_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+    return (int64_t)c1_blocks(N * H * W) * (Cout * Cin + Cout) * 4;
+}
+
+extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                 const float* w, int64_t Cout, void* gin, float* gw, float* gbias, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(in && gout && w && gw && gbias && ws, "conv1x1_bwd: null pointer");
+    MISEG_REQUIRE(Cin == 16, "conv1x1_bwd: Cin must be 16");
+    MISEG_REQUIRE(ws_bytes >= miseg_conv1x1_bwd_ws_bytes(N, H, W, Cin, Cout), "conv1x1_bwd: workspace too small");
+    const int64_t npix = N * H * W;
+    const int nb = c1_blocks(npix);
+    hipStream_t st = as_stream(stream);
+#define L(CO)                                                                                                                                  \
+    if (dt == MISEG_F32) hipLaunchKernelGGL((conv1x1_bwd_kernel<float, 16, CO>), dim3(nb), dim3(256), 0, st, (const float*)in, gout, npix, w, (float*)gin, (float*)ws); \
+    else hipLaunchKernelGGL((conv1x1_bwd_kernel<bf16, 16, CO>), dim3(nb), dim3(256), 0, st, (const bf16*)in, gout, npix, w, (bf16*)gin, (float*)ws)
+    switch (Cout) {
+        case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break;
+        case 5: L(5); break; case 8: L(8); break;
+        default: return fail(MISEG_E_INVALID, "conv1x1_bwd: unsupported Cout %ld", (long)Cout);
+    }
+#undef L
+    MISEG_LAUNCH_CHECK("conv1x1_bwd_kernel");
+    const int len = (int)(Cout * Cin + Cout);
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, len, (int)(Cout * Cin), gw, gbias);
+    MISEG_LAUNCH_CHECK("sum_parts2_kernel");
+    return MISEG_OK;
+}

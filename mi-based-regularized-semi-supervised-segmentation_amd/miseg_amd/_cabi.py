@@ -1,0 +1,89 @@
+"""ctypes binding of the gfx950 C-ABI library (include/miseg_hip.h).
+
+The prototypes are read from the header itself, so the Python side can never drift from the
+declared ABI, and ``declared_symbols()`` lets the CPU test-suite check that the built library
+exports every entry point.  There is NO fallback: if the library is missing or a kernel call
+fails, the product raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+HEADER = os.path.join(REPO_ROOT, "include", "miseg_hip.h")
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmiseg_hip.so")
+
+F32, BF16 = 0, 1
+
+_CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "void": None}
+
+
+def _parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int64_t|int|const char\s*\*)\s+(miseg_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if "char" in ret else _CTYPES[ret]
+        argtypes = []
+        args = args.strip()
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPES[base])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+PROTOTYPES = _parse_header()
+
+
+def declared_symbols() -> List[str]:
+    return sorted(PROTOTYPES)
+
+
+class MisegError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) the in-tree library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MisegError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                             f"`make -C {os.path.join(PKG_ROOT, 'csrc')}` -- there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point and turn a negative status into an exception."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        msg = lib().miseg_last_error()
+        raise MisegError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def query(name: str, *args) -> int:
+    v = getattr(lib(), name)(*args)
+    if v < 0:
+        raise MisegError(f"{name}{args} -> {v}: unsupported configuration")
+    return int(v)

@@ -1,0 +1,119 @@
+"""Data-parallel gradient reduction: one process per GPU, RCCL over xGMI (torch.distributed backend "nccl").
+
+The reference has no distributed code at all; this is the MI355X-native addition the
+north star asks for.  Semantics: every rank draws its own labeled/unlabeled minibatch and runs
+the full step locally -- BatchNorm statistics and the K x K joints stay per-rank, exactly what the reference
+computes for one process with that batch -- then the gradients of all parameters are mean-all-reduced before
+``Adam.step``.
+
+Design for point-to-point xGMI rather than NVSwitch: the whole gradient is only 8.76 MB (2.19 M fp32), so ring
+all-reduce is latency-bound, not bandwidth-bound.  Gradients live in ONE flat buffer (``miseg_amd.flat``), cut
+into a few large contiguous buckets ordered by reverse execution (heads + decoder first).  A bucket's
+all-reduce is issued asynchronously from the autograd hook of its last-arriving parameter, so it overlaps the
+rest of the backward pass on RCCL's own stream; ``finish()`` waits, and averages.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .flat import FlatBuffers
+
+
+def init_from_env(backend: Optional[str] = None) -> bool:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns True if world_size > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return True
+
+
+class GradReducer:
+    def __init__(self, flat: FlatBuffers, num_buckets: int = 3, process_group=None, broadcast_params: bool = True):
+        assert dist.is_initialized(), "call ddp.init_from_env() first"
+        self.flat = flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        flat.ensure()
+        self._avg_native = dist.get_backend(process_group) == "nccl"
+        # contiguous buckets over the flat buffer, cut at parameter boundaries; bucket 0 = tail (ready first)
+        n = len(flat.params)
+        target = flat.total / float(num_buckets)
+        bounds, acc = [n], 0.0
+        for i in range(n - 1, -1, -1):
+            acc += (flat.offsets[i + 1] if i + 1 < n else flat.total) - flat.offsets[i]
+            if acc >= target and len(bounds) < num_buckets and i > 0:
+                bounds.append(i)
+                acc = 0.0
+        bounds.append(0)
+        self.buckets = []  # (first_param, last_param_exclusive, start, end)
+        for hi, lo in zip(bounds[:-1], bounds[1:]):
+            if lo < hi:
+                end = flat.offsets[hi] if hi < n else flat.total
+                self.buckets.append((lo, hi, flat.offsets[lo], end))
+        self._bucket_of = [0] * n
+        for b, (lo, hi, _, _) in enumerate(self.buckets):
+            for i in range(lo, hi):
+                self._bucket_of[i] = b
+        self._pending: List[int] = []
+        self._handles: List[Optional[object]] = []
+        self._armed = False
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        if broadcast_params:
+            dist.broadcast(flat.flat_param, src=0, group=process_group)
+
+    def _make_hook(self, index: int):
+        def hook(_param):
+            if not self._armed:
+                return
+            b = self._bucket_of[index]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int) -> None:
+        _, _, start, end = self.buckets[b]
+        view = self.flat.flat_grad[start:end]
+        op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
+        self._handles[b] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+
+    def prepare(self) -> None:
+        """Call after zero_grad(), before backward()."""
+        self.flat.ensure()
+        self._pending = [hi - lo for lo, hi, _, _ in self.buckets]
+        self._handles = [None] * len(self.buckets)
+        self._armed = True
+
+    def finish(self) -> None:
+        """Call after backward(), before optimizer.step(): flush unlaunched buckets, wait, average."""
+        self._armed = False
+        for b in range(len(self.buckets)):
+            if self._handles[b] is None:  # some parameter of the bucket got no gradient this step
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if not self._avg_native:
+            self.flat.flat_grad.div_(self.world)
+
+
+def attach(trainer, num_buckets: int = 3) -> Optional[GradReducer]:
+    """Give a SemiTrainer (after ``init()`` and after its parameters are on their device) a GradReducer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    optimizer = trainer._optimizer
+    if not hasattr(optimizer, "flat"):
+        raise RuntimeError("data-parallel training needs the flat-buffer FusedAdam (Optim.name: Adam)")
+    trainer.to(trainer._device)
+    trainer._grad_reducer = GradReducer(optimizer.flat, num_buckets=num_buckets)
+    return trainer._grad_reducer

@@ -1,0 +1,169 @@
+"""Flat parameter / gradient storage and the fused Adam that runs on it.
+
+All trainable tensors of the step (U-Net + projector heads, 2.19 M fp32 values at the shipped config)
+are re-pointed into ONE contiguous fp32 buffer, their ``.grad`` into a second one.  That gives
+  * the optimiser a single HIP launch per step (``miseg_adam_step``; ref semi_seg/trainer.py:67-72,179-184
+    configures torch.optim.Adam with L2 weight decay -- same update rule, same state_dict layout);
+  * data-parallel training a handful of large contiguous RCCL all-reduces instead of ~70 small ones
+    (``miseg_amd.ddp.GradReducer`` buckets are slices of the flat gradient).
+``torch.optim.Optimizer`` is subclassed so schedulers, ``param_groups`` and checkpoints behave as usual.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional
+
+import torch
+from torch import Tensor
+
+from . import unet_ops
+
+
+class FlatBuffers:
+    """Owns the flat param / grad buffers of a list of parameters (all on one GPU, fp32)."""
+
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.flat_param: Optional[Tensor] = None
+        self.flat_grad: Optional[Tensor] = None
+        self.offsets: List[int] = []
+        self.total = 0
+
+    def valid(self) -> bool:
+        if self.flat_param is None:
+            return False
+        first, last = self.params[0], self.params[-1]
+        base = self.flat_param.data_ptr()
+        return first.data_ptr() == base and last.data_ptr() == base + 4 * self.offsets[-1] and \
+            (last.grad is not None and last.grad.data_ptr() == self.flat_grad.data_ptr() + 4 * self.offsets[-1])
+
+    def build(self) -> None:
+        dev = self.params[0].device  # any device: the reducer's bucketing is also exercised on CPU/gloo in the tests;
+        # the fused Adam kernel itself is GPU-only and raises on CPU tensors
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("flat buffers need fp32 parameters on a single device")
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        self.total = off
+        flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = flat_p[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                gview = flat_g[o:o + p.numel()].view_as(p)
+                if p.grad is not None:
+                    gview.copy_(p.grad)
+                p.data = view
+                p.grad = gview
+        self.flat_param, self.flat_grad = flat_p, flat_g
+
+    def ensure(self) -> None:
+        if not self.valid():
+            self.build()
+
+    def zero_grad(self) -> None:
+        self.ensure()
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):  # re-attach views dropped by set_to_none-style code
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (amsgrad=False) as one fused HIP launch over flat buffers."""
+
+    def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented in the fused HIP Adam")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._flats: List[FlatBuffers] = [FlatBuffers(list(g["params"])) for g in self.param_groups]
+        self._steps = [0 for _ in self.param_groups]
+        self._m: List[Optional[Tensor]] = [None] * len(self.param_groups)
+        self._v: List[Optional[Tensor]] = [None] * len(self.param_groups)
+        self._hyper: List[Optional[Tensor]] = [None] * len(self.param_groups)
+        self._pending_state: Optional[dict] = None
+
+    @property
+    def flat(self) -> FlatBuffers:
+        return self._flats[0]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for fb in self._flats:
+            fb.zero_grad()
+
+    def _ensure_state(self, gi: int) -> None:
+        fb = self._flats[gi]
+        rebuilt = not fb.valid()
+        fb.ensure()
+        if self._m[gi] is None or rebuilt and self._m[gi].numel() != fb.total or self._m[gi].device != fb.flat_param.device:
+            self._m[gi] = torch.zeros_like(fb.flat_param)
+            self._v[gi] = torch.zeros_like(fb.flat_param)
+            self._hyper[gi] = torch.zeros(4, dtype=torch.float32, device=fb.flat_param.device)
+        if self._pending_state is not None:
+            self._apply_state(self._pending_state)
+            self._pending_state = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            self._ensure_state(gi)
+            fb = self._flats[gi]
+            self._steps[gi] += 1
+            t = self._steps[gi]
+            b1, b2 = group["betas"]
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            host = torch.tensor([group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]], dtype=torch.float32)
+            self._hyper[gi].copy_(host, non_blocking=True)
+            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2)
+        return loss
+
+    # ---- torch.optim.Adam-compatible checkpoints (per-parameter exp_avg / exp_avg_sq / step)
+    def state_dict(self) -> dict:
+        state: Dict[int, dict] = {}
+        groups = []
+        idx = 0
+        for gi, group in enumerate(self.param_groups):
+            fb = self._flats[gi]
+            ids = []
+            for pi, p in enumerate(fb.params):
+                if self._m[gi] is not None and fb.offsets:
+                    o = fb.offsets[pi]
+                    state[idx] = {"step": torch.tensor(float(self._steps[gi])),
+                                  "exp_avg": self._m[gi][o:o + p.numel()].view_as(p).clone(),
+                                  "exp_avg_sq": self._v[gi][o:o + p.numel()].view_as(p).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in group.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def _apply_state(self, sd: dict) -> None:
+        idx = 0
+        for gi in range(len(self.param_groups)):
+            fb = self._flats[gi]
+            for pi, p in enumerate(fb.params):
+                st = sd["state"].get(idx, sd["state"].get(str(idx)))
+                if st is not None:
+                    o = fb.offsets[pi]
+                    self._m[gi][o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                    self._v[gi][o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                    self._steps[gi] = int(float(st["step"]))
+                idx += 1
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        for group, saved in zip(self.param_groups, state_dict["param_groups"]):
+            for k, v in saved.items():
+                if k != "params":
+                    group[k] = v
+        if all(fb.params[0].is_cuda for fb in self._flats):
+            for gi in range(len(self.param_groups)):
+                self._ensure_state(gi)
+            self._apply_state(state_dict)
+        else:
+            self._pending_state = state_dict  # applied once the parameters live on the GPU

@@ -1,0 +1,348 @@
+"""torch.autograd front-ends of the HIP kernels (thin: pointer/shape plumbing only).
+
+Every function here requires CUDA(HIP) tensors and raises otherwise -- the product has no CPU or
+eager-PyTorch fallback.  PyTorch supplies device memory, the current HIP stream and autograd
+bookkeeping; all arithmetic happens in ``csrc/*.hip`` behind ``include/miseg_hip.h``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _cabi
+from ._cabi import BF16, F32, call, query
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _cabi.MisegError("miseg_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def flips_to_tensor(decisions: Sequence[Sequence[bool]], device) -> Tensor:
+    """[[flip_h, flip_w], ...] -> int32 bit masks (bit0 = H, bit1 = W)."""
+    return torch.tensor([int(bool(fh)) | (int(bool(fw)) << 1) for fh, fw in decisions], dtype=torch.int32, device=device)
+
+
+# ------------------------------------------------------------------------------------------ local MI
+def colour_windows(windows: Sequence[Tuple[int, int, int, int]]) -> List[List[int]]:
+    """Greedy colouring of overlapping windows into pairwise-disjoint groups (deterministic backward:
+    each group is one launch with plain read-modify-write, groups run in stream order)."""
+    groups: List[List[int]] = []
+    for idx, (h0, h1, w0, w1) in enumerate(windows):
+        for grp in groups:
+            if all(h1 <= windows[j][0] or windows[j][1] <= h0 or w1 <= windows[j][2] or windows[j][3] <= w0 for j in grp):
+                grp.append(idx)
+                break
+        else:
+            groups.append([idx])
+    return groups
+
+
+class _LocalMI(torch.autograd.Function):
+    """loss[P] of IIDSegmentationLoss over P windows (ref: contrastyou/losses/iic_loss.py:107-149)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, y: Tensor, mask: Optional[Tensor], pad: int, windows, lamda: float):
+        _need_gpu(x, y, mask)
+        x, y = x.contiguous().float(), y.contiguous().float()
+        mask = None if mask is None else mask.contiguous().float()
+        n, k, h, w = x.shape
+        p = len(windows)
+        dev = x.device
+        win = torch.tensor(windows, dtype=torch.int32, device=dev).view(p, 4)
+        t = 2 * pad + 1
+        raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=dev)
+        ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), dev)
+        call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
+             _ptr(ws), ws.numel())
+        loss = torch.empty(p, dtype=torch.float32, device=dev)
+        grad_raw = torch.empty_like(raw)
+        call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
+        ctx.save_for_backward(x, y, mask, grad_raw, win)
+        ctx.pad, ctx.windows = pad, list(windows)
+        ctx.raw = raw
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss: Tensor):
+        x, y, mask, grad_raw, win = ctx.saved_tensors
+        n, k, h, w = x.shape
+        gx, gy = torch.zeros_like(x), torch.zeros_like(y)
+        scale = gloss.contiguous().float()
+        for grp in colour_windows(ctx.windows):
+            if len(grp) == len(ctx.windows):
+                gwin, ggrad, gscale = win, grad_raw, scale
+            else:
+                idx = torch.tensor(grp, dtype=torch.long, device=x.device)
+                gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[idx].contiguous(), scale[idx].contiguous()
+            call("miseg_iic_local_bwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, ctx.pad, _ptr(gwin), len(grp),
+                 _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy))
+        return gx, gy, None, None, None, None
+
+
+def local_mi_losses(x: Tensor, y: Tensor, pad: int, windows, lamda: float = 1.0, mask: Optional[Tensor] = None) -> Tensor:
+    return _LocalMI.apply(x, y, mask, int(pad), [tuple(int(v) for v in w) for w in windows], float(lamda))
+
+
+def local_mi_raw_joint(x: Tensor, y: Tensor, pad: int, windows, mask: Optional[Tensor] = None) -> Tensor:
+    """raw[P][T][T][K][K] only (no autograd) -- exposed for parity tests of the contraction."""
+    _need_gpu(x, y, mask)
+    x, y = x.contiguous().float(), y.contiguous().float()
+    n, k, h, w = x.shape
+    p = len(windows)
+    win = torch.tensor(windows, dtype=torch.int32, device=x.device).view(p, 4)
+    t = 2 * pad + 1
+    raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=x.device)
+    ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), x.device)
+    call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
+         _ptr(ws), ws.numel())
+    return raw
+
+
+# ------------------------------------------------------------------------------------------ global MI
+class _GlobalMI(torch.autograd.Function):
+    """IIDLoss for S sub-heads at once: x, y [S,N,K] -> (loss[S], loss_no_lamb[S], joint[S,K,K])."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, y: Tensor, lamb: float):
+        _need_gpu(x, y)
+        x, y = x.contiguous().float(), y.contiguous().float()
+        s, n, k = x.shape
+        loss = torch.empty(s, dtype=torch.float32, device=x.device)
+        loss_nl = torch.empty_like(loss)
+        joint = torch.empty(s, k, k, dtype=torch.float32, device=x.device)
+        call("miseg_iic_global_fwd", _stream(), _ptr(x), _ptr(y), s, n, k, float(lamb), _ptr(loss), _ptr(loss_nl), _ptr(joint))
+        ctx.save_for_backward(x, y)
+        ctx.lamb = float(lamb)
+        ctx.mark_non_differentiable(loss_nl, joint)
+        return loss, loss_nl, joint
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g2):
+        x, y = ctx.saved_tensors
+        s, n, k = x.shape
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        up = gloss.contiguous().float()
+        call("miseg_iic_global_bwd", _stream(), _ptr(x), _ptr(y), s, n, k, ctx.lamb, _ptr(up), _ptr(gx), _ptr(gy))
+        return gx, gy, None
+
+
+def global_mi(x: Tensor, y: Tensor, lamb: float = 1.0):
+    return _GlobalMI.apply(x, y, float(lamb))
+
+
+# ------------------------------------------------------------------------------------------ heads
+def as_nhwc(t: Tensor) -> Tensor:
+    """[N,C,H,W]-shaped tensor whose memory is NHWC (channels_last); converts if needed."""
+    if t.dim() != 4:
+        raise ValueError(f"expected NCHW-shaped tensor, got {tuple(t.shape)}")
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(n, c, h, w, dtype, device) -> Tensor:
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def zeros_nhwc(n, c, h, w, dtype, device) -> Tensor:
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last).zero_()
+
+
+class _LocalHead(torch.autograd.Function):
+    """S x (1x1 conv + channel softmax) with fused sample gather + flip replay -> prob [S,M,K,H,W]."""
+
+    @staticmethod
+    def forward(ctx, feat: Tensor, w: Tensor, b: Tensor, src: Tensor, flips: Optional[Tensor], temperature: float):
+        _need_gpu(feat, w, b, src, flips)
+        feat = as_nhwc(feat)
+        bsz, c, h, wd = feat.shape
+        s, k, _ = w.shape
+        m = src.numel()
+        w, b = w.contiguous().float(), b.contiguous().float()
+        prob = torch.empty(s, m, k, h, wd, dtype=torch.float32, device=feat.device)
+        call("miseg_head_local_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), _ptr(b),
+             s, k, float(temperature), _ptr(prob))
+        ctx.save_for_backward(feat, w, src, flips, prob)
+        ctx.temperature = float(temperature)
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob: Tensor):
+        feat, w, src, flips, prob = ctx.saved_tensors
+        bsz, c, h, wd = feat.shape
+        s, k, _ = w.shape
+        m = src.numel()
+        gprob = gprob.contiguous().float()
+        gfeat = zeros_nhwc(bsz, c, h, wd, feat.dtype, feat.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(s, k, dtype=torch.float32, device=feat.device)
+        ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
+        call("miseg_head_local_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
+             ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel())
+        return gfeat, gw, gb, None, None, None
+
+
+def local_head(feat: Tensor, w: Tensor, b: Tensor, src: Tensor, flips: Optional[Tensor], temperature: float = 1.0) -> Tensor:
+    return _LocalHead.apply(feat, w, b, src, flips, float(temperature))
+
+
+class _GlobalHead(torch.autograd.Function):
+    """S x (global avg pool -> Linear -> softmax) -> prob [S,M,K]."""
+
+    @staticmethod
+    def forward(ctx, feat: Tensor, w: Tensor, b: Tensor, src: Tensor, temperature: float):
+        _need_gpu(feat, w, b, src)
+        feat = as_nhwc(feat)
+        bsz, c, h, wd = feat.shape
+        s, k, _ = w.shape
+        m = src.numel()
+        w, b = w.contiguous().float(), b.contiguous().float()
+        pooled = torch.empty(m, c, dtype=torch.float32, device=feat.device)
+        prob = torch.empty(s, m, k, dtype=torch.float32, device=feat.device)
+        call("miseg_head_global_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), m, _ptr(w), _ptr(b), s, k,
+             float(temperature), _ptr(pooled), _ptr(prob))
+        ctx.save_for_backward(w, src, pooled, prob)
+        ctx.meta = (bsz, c, h, wd, feat.dtype, float(temperature))
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob: Tensor):
+        w, src, pooled, prob = ctx.saved_tensors
+        bsz, c, h, wd, dtype, temperature = ctx.meta
+        s, k, _ = w.shape
+        m = src.numel()
+        gprob = gprob.contiguous().float()
+        gfeat = zeros_nhwc(bsz, c, h, wd, dtype, w.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(s, k, dtype=torch.float32, device=w.device)
+        dz = torch.empty(s * m * k, dtype=torch.float32, device=w.device)
+        call("miseg_head_global_bwd", _stream(), _DT[dtype], bsz, h, wd, c, _ptr(src), m, _ptr(w), s, k, temperature, _ptr(pooled),
+             _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(dz))
+        return gfeat, gw, gb, None, None
+
+
+def global_head(feat: Tensor, w: Tensor, b: Tensor, src: Tensor, temperature: float = 1.0) -> Tensor:
+    return _GlobalHead.apply(feat, w, b, src, float(temperature))
+
+
+# ------------------------------------------------------------------------------------------ pixel losses
+def _logits_nhwc(t: Tensor) -> Tensor:
+    t = as_nhwc(t)
+    return t if t.dtype == torch.float32 else t.float()
+
+
+class _SoftmaxKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, labels: Tensor):
+        _need_gpu(logits, labels)
+        logits = _logits_nhwc(logits)
+        n, c, h, w = logits.shape
+        labels = labels.contiguous().view(n, h, w)
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        dev = logits.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        glogits = empty_nhwc(n, c, h, w, torch.float32, dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = _ws(query("miseg_loss_ws_bytes", n, h, w), dev)
+        call("miseg_softmax_kl", _stream(), _ptr(logits), _ptr(labels), n, h, w, c, None, _ptr(loss), _ptr(glogits), _ptr(bad),
+             _ptr(ws), ws.numel())
+        ctx.save_for_backward(glogits)
+        ctx.bad = bad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (glogits,) = ctx.saved_tensors
+        return glogits * g, None
+
+
+def softmax_kl(logits: Tensor, labels: Tensor, check_labels: bool = True) -> Tensor:
+    """KL_div(softmax(logits), class2one_hot(labels)) with reduction='mean'."""
+    return _SoftmaxKL.apply(logits, labels)
+
+
+class _SoftmaxMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, flips: Optional[Tensor]):
+        _need_gpu(a, b, flips)
+        a, b = _logits_nhwc(a), _logits_nhwc(b.detach())
+        n, c, h, w = a.shape
+        dev = a.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ga = empty_nhwc(n, c, h, w, torch.float32, dev)
+        ws = _ws(query("miseg_loss_ws_bytes", n, h, w), dev)
+        call("miseg_softmax_mse", _stream(), _ptr(a), _ptr(b), _ptr(flips), n, h, w, c, None, _ptr(loss), _ptr(ga), _ptr(ws), ws.numel())
+        ctx.save_for_backward(ga)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (ga,) = ctx.saved_tensors
+        return ga * g, None, None
+
+
+def softmax_mse(a: Tensor, b: Tensor, flips: Optional[Tensor] = None) -> Tensor:
+    """mean((softmax(a) - softmax(flip(b)).detach())**2); ``flips`` replays the per-sample flip on b."""
+    return _SoftmaxMSE.apply(a, b, flips)
+
+
+def _flip_raw(x: Tensor, flips: Tensor) -> Tensor:
+    _need_gpu(x, flips)
+    if x.element_size() not in (2, 4, 8):
+        raise ValueError("flip: element size must be 2, 4 or 8 bytes")
+    out = torch.empty_like(x)
+    n, c, h, w = x.shape
+    ist = torch.tensor(x.stride(), dtype=torch.int64)   # host arrays, read on the host side of the C call
+    ost = torch.tensor(out.stride(), dtype=torch.int64)
+    call("miseg_flip", _stream(), _ptr(x), _ptr(out), n, c, h, w, ist.data_ptr(), ost.data_ptr(), x.element_size(), _ptr(flips))
+    return out
+
+
+class _Flip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, flips: Tensor):
+        ctx.save_for_backward(flips)
+        return _flip_raw(x, flips)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (flips,) = ctx.saved_tensors
+        return _flip_raw(g, flips), None  # a flip is its own inverse
+
+
+def flip(x: Tensor, flips: Tensor) -> Tensor:
+    """Per-sample H/W flip of an [N,C,H,W]-shaped tensor (any strides; 2/4/8-byte elements), bit-exact."""
+    return _Flip.apply(x, flips) if x.requires_grad else _flip_raw(x, flips)
+
+
+def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True):
+    """argmax over channels and per-sample per-class (intersection, union) int64 counts."""
+    _need_gpu(logits, labels)
+    logits = _logits_nhwc(logits)
+    n, c, h, w = logits.shape
+    dev = logits.device
+    pred = torch.empty(n, h, w, dtype=torch.int64, device=dev) if want_pred else None
+    inter = uni = None
+    if labels is not None:
+        labels = labels.contiguous().view(n, h, w).long()
+        inter = torch.empty(n, c, dtype=torch.int64, device=dev)
+        uni = torch.empty(n, c, dtype=torch.int64, device=dev)
+    call("miseg_argmax_dice", _stream(), _ptr(logits), _ptr(labels), n, h, w, c, _ptr(pred), _ptr(inter), _ptr(uni))
+    return pred, inter, uni

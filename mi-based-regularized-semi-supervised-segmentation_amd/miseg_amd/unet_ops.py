@@ -1,0 +1,167 @@
+"""Autograd front-ends of the U-Net kernels: conv3x3 + BatchNorm(train/eval) + ReLU (+ fused 2x2
+max-pool, + fused nearest-x2 upsample / skip concat on the input side) and the 1x1 logits head.
+
+ref: contrastyou/arch/unet.py:10-40 (conv_block / up_conv), :61-64 (pools), :84,129 (DeConv_1x1),
+:109-125 (torch.cat skips).  Activations are [N,C,H,W]-shaped torch tensors in channels_last memory
+(= the NHWC layout of the kernels) of dtype float32 (exact mode) or bfloat16.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._cabi import call, query
+from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def vec_of(dtype) -> int:
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def stem_input(image: Tensor, dtype) -> Tensor:
+    """fp32 [B,Cin,H,W] image -> [B,VEC,H,W] channels_last tensor of ``dtype`` (extra channels zero)."""
+    _need_gpu(image)
+    b, cin, h, w = image.shape
+    image = as_nhwc(image.float())
+    cp = vec_of(dtype)
+    cp = ((cin + cp - 1) // cp) * cp
+    out = empty_nhwc(b, cp, h, w, dtype, image.device)
+    call("miseg_cast_pad", _stream(), _ptr(image), b * h * w, cin, _DT[dtype], _ptr(out), cp)
+    return out
+
+
+def _pack(weight: Tensor, dtype, kind: int, ci_begin: int = 0, ci_count: int = 0) -> Tensor:
+    cout, cin = weight.shape[0], weight.shape[1]
+    n = (ci_count if kind else cout) * (cout if kind else cin) * 9
+    packed = torch.empty(n, dtype=dtype, device=weight.device)
+    call("miseg_pack_conv3x3_weights", _stream(), _DT[dtype], _ptr(weight), cout, cin, kind, ci_begin, ci_count, _ptr(packed))
+    return packed
+
+
+class _ConvBNReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor,
+                running_var: Tensor, nbt: Tensor, training: bool, ups0: int, ups1: int, want_pool: bool):
+        _need_gpu(x0, x1, weight)
+        x0 = as_nhwc(x0)
+        dtype, dev = x0.dtype, x0.device
+        n, c0 = x0.shape[0], x0.shape[1]
+        h, w = x0.shape[2] << ups0, x0.shape[3] << ups0
+        c1 = 0
+        if x1 is not None:
+            x1 = as_nhwc(x1)
+            c1 = x1.shape[1]
+            assert x1.dtype == dtype and (x1.shape[2] << ups1, x1.shape[3] << ups1) == (h, w)
+        cout = weight.shape[0]
+        assert weight.shape[1] == c0 + c1, (weight.shape, c0, c1)
+        weight = weight.contiguous().float()
+        packed = _pack(weight, dtype, 0)
+        raw = empty_nhwc(n, cout, h, w, dtype, dev)
+        saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
+        if training:
+            parts = query("miseg_conv3x3_stats_parts", n, h, w)
+            stats = torch.empty(parts * 2 * cout, dtype=torch.float32, device=dev)
+        else:
+            parts, stats = 0, None
+        call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
+             _ptr(stats))
+        if training:
+            call("miseg_bn_finalize", _stream(), _ptr(stats), parts, cout, n * h * w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
+                 _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved))
+        else:
+            call("miseg_bn_eval_coeffs", _stream(), cout, _ptr(gamma), _ptr(beta), BN_EPS, _ptr(running_mean), _ptr(running_var), _ptr(saved))
+        y = empty_nhwc(n, cout, h, w, dtype, dev)
+        pooled = empty_nhwc(n, cout, h // 2, w // 2, dtype, dev) if want_pool else None
+        call("miseg_bn_relu_fwd", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(saved), _ptr(y), _ptr(pooled))
+        ctx.save_for_backward(x0, x1, weight, gamma, raw, y, saved)
+        ctx.cfg = (training, ups0, ups1, want_pool, c0, c1, n, h, w, cout)
+        if want_pool:
+            return y, pooled
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy: Optional[Tensor], gpool: Optional[Tensor]):
+        x0, x1, weight, gamma, raw, y, saved = ctx.saved_tensors
+        training, ups0, ups1, want_pool, c0, c1, n, h, w, cout = ctx.cfg
+        dtype, dev = raw.dtype, raw.device
+        if gy is None and gpool is None:
+            return (None,) * 12
+        gy = None if gy is None else as_nhwc(gy.to(dtype))
+        gpool = None if gpool is None else as_nhwc(gpool.to(dtype))
+        graw = empty_nhwc(n, cout, h, w, dtype, dev)
+        ggamma = torch.empty(cout, dtype=torch.float32, device=dev)
+        gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+        ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
+        call("miseg_bn_relu_bwd", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
+             int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel())
+        gw = None
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty_like(weight)
+            ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
+            call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
+                 _ptr(ws2), ws2.numel())
+        grads = [None, None]
+        for s, (cb, cs, ups, xs) in enumerate(((0, c0, ups0, x0), (c0, c1, ups1, x1))):
+            if xs is None or not ctx.needs_input_grad[s]:
+                continue
+            packed = _pack(weight, dtype, 1, cb, cs)
+            gfull = empty_nhwc(n, cs, h, w, dtype, dev)
+            call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(graw), cout, 0, None, 0, 0, n, h, w, _ptr(packed), cs, _ptr(gfull), None)
+            if ups:
+                glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
+                call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)
+                gfull = glow
+            grads[s] = gfull
+        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None
+
+
+def conv_bn_relu(x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor,
+                 running_var: Tensor, nbt: Tensor, training: bool, ups0: int = 0, ups1: int = 0,
+                 want_pool: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    return _ConvBNReLU.apply(x0, x1, weight, gamma, beta, running_mean, running_var, nbt, bool(training), int(ups0), int(ups1),
+                             bool(want_pool))
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor):
+        _need_gpu(x, weight, bias)
+        x = as_nhwc(x)
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        wf = weight.contiguous().float().view(cout, cin)
+        bf = bias.contiguous().float()
+        out = empty_nhwc(n, cout, h, w, torch.float32, x.device)
+        call("miseg_conv1x1_fwd", _stream(), _DT[x.dtype], _ptr(x), n, h, w, cin, _ptr(wf), _ptr(bf), cout, _ptr(out))
+        ctx.save_for_backward(x, wf)
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        x, wf = ctx.saved_tensors
+        n, cin, h, w = x.shape
+        cout = wf.shape[0]
+        gout = as_nhwc(gout.float())
+        gin = empty_nhwc(n, cin, h, w, x.dtype, x.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(wf)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        ws = _ws(query("miseg_conv1x1_bwd_ws_bytes", n, h, w, cin, cout), x.device)
+        call("miseg_conv1x1_bwd", _stream(), _DT[x.dtype], _ptr(x), _ptr(gout), n, h, w, cin, _ptr(wf), cout, _ptr(gin), _ptr(gw), _ptr(gb),
+             _ptr(ws), ws.numel())
+        return gin, gw.view(ctx.wshape), gb
+
+
+def conv1x1(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    return _Conv1x1.apply(x, weight, bias)
+
+
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, hyper: Tensor, beta1: float, beta2: float) -> None:
+    """Fused Adam on flat fp32 buffers; ``hyper`` = device fp32[4] (lr/bc1, 1/sqrt(bc2), eps, weight_decay)."""
+    _need_gpu(param, grad, exp_avg, exp_avg_sq, hyper)
+    call("miseg_adam_step", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1), float(beta2),
+         _ptr(hyper))

@@ -1,0 +1,328 @@
+"""Train / eval epochers of the semi-supervised segmentation step on the MI355X kernels.
+
+Drop-in for ref ``semi_seg/epocher.py``: same classes, constructor signatures and meter names
+(``lr, sup_loss, reg_loss, sup_dice{DSC1..,DSC_mean}, mi, individual_mis{<feature>}, uda, iic_weight,
+uda_weight``).  One step = one U-Net forward on cat[labeled, unlabeled, flip(unlabeled)], supervised KL,
+regulariser, one backward, Adam (ref :137-188).  What changed underneath:
+
+* the per-sample ``clone().flip()`` Python loops (ref :148-149, :160-161, :264-266) became index math:
+  decisions are still drawn from Python's ``random`` under ``FixRandomSeed(seed)`` in the reference's
+  order, packed into an int32 bit-mask tensor and applied inside the consuming kernels;
+* ``softmax -> one-hot -> KL`` (ref :165-166) and ``softmax, softmax -> MSE`` (ref :221-224) are single
+  fused kernels with fused backward;
+* slicing / chunking / cat of tapped features and the five sub-heads (ref :258-273) are one gather-fused
+  launch per tap; the IIC losses run on the MFMA joint kernels;
+* the ~7 ``.item()`` host syncs per iteration (ref :182-185, :225, :278-282) are ONE device-to-host copy
+  of all meter scalars.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import List, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from contrastyou.epocher._utils import preprocess_input_with_single_transformation  # noqa
+from contrastyou.epocher._utils import preprocess_input_with_twice_transformation  # noqa
+from contrastyou.helper import average_iter, weighted_average_iter
+from contrastyou.trainer._utils import ClusterHead  # noqa
+from deepclustering2.augment.tensor_augment import TensorRandomFlip
+from deepclustering2.decorator import FixRandomSeed
+from deepclustering2.epoch import _Epocher  # noqa
+from deepclustering2.loss import KL_div
+from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterInterface, MultipleAverageValueMeter, UniversalDice)
+from deepclustering2.optim import get_lrs_from_optimizer
+from deepclustering2.type import T_loader, T_loss, T_optim
+from deepclustering2.utils import class2one_hot
+from miseg_amd import ops
+from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
+
+_DEBUG_ASSERTS = os.environ.get("MISEG_ASSERTS", "0") == "1"
+
+
+def _fused(fn):
+    fn._miseg_fused = True
+    return fn
+
+
+class _num_class_mixin:
+    _model: nn.Module
+
+    @property
+    def num_classes(self):
+        return self._model.num_classes
+
+
+class _Pending:
+    """Device scalars whose host values are fetched with a single synchronising copy per iteration."""
+
+    def __init__(self):
+        self._names: List[str] = []
+        self._vals: List[Tensor] = []
+
+    def put(self, name: str, value: Tensor) -> None:
+        self._names.append(name)
+        self._vals.append(value.detach().reshape(()).float())
+
+    def fetch(self) -> dict:
+        if not self._vals:
+            return {}
+        host = torch.stack(self._vals).tolist()
+        out = dict(zip(self._names, host))
+        self._names, self._vals = [], []
+        return out
+
+
+class EvalEpocher(_num_class_mixin, _Epocher):
+    """Per-patient evaluation: KL loss + 3D Dice (ref :36-73)."""
+
+    def __init__(self, model, val_loader: T_loader, sup_criterion: T_loss, cur_epoch=0, device="cpu") -> None:
+        super().__init__(model, num_batches=len(val_loader), cur_epoch=cur_epoch, device=device)
+        self._val_loader = val_loader
+        self._sup_criterion = sup_criterion
+
+    def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters.register_meter("loss", AverageValueMeter())
+        meters.register_meter("dice", UniversalDice(self.num_classes, report_axises=list(range(1, self.num_classes))))
+        return meters
+
+    @torch.no_grad()
+    def _run(self, *args, **kwargs) -> Tuple[EpochResultDict, float]:
+        self._model.eval()
+        report_dict = EpochResultDict()
+        for _, val_data in zip(self._indicator, self._val_loader):
+            val_img, val_target, _file_path, _, group = self._unzip_data(val_data, self._device)
+            val_logits = self._model(val_img)
+            labels = val_target.squeeze(1)
+            if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
+                val_loss = self._sup_criterion.from_logits(val_logits, labels)
+            else:
+                val_loss = self._sup_criterion(val_logits.softmax(1), class2one_hot(labels, self.num_classes), disable_assert=True)
+            _, inter, union = ops.argmax_dice(val_logits, labels, want_pred=False)
+            self.meters["loss"].add(val_loss.item())
+            self.meters["dice"].add_counts(inter, union, group_name=group)
+            report_dict = self.meters.tracking_status()
+            self._indicator.set_postfix_dict(report_dict)
+        return report_dict, self.meters["dice"].summary()["DSC_mean"]
+
+    @staticmethod
+    def _unzip_data(data, device):
+        return preprocess_input_with_single_transformation(data, device)
+
+
+class TrainEpocher(_num_class_mixin, _Epocher):
+    """Supervised-only (``partial``) step (ref :110-197); the semi-supervised epochers add ``regularization``."""
+
+    def __init__(self, model, optimizer: T_optim, labeled_loader: T_loader, unlabeled_loader: T_loader, sup_criterion: T_loss,
+                 reg_weight: float, num_batches: int, cur_epoch=0, device="cpu", feature_position=None,
+                 feature_importance=None) -> None:
+        super().__init__(model, num_batches=num_batches, cur_epoch=cur_epoch, device=device)
+        self._optimizer = optimizer
+        self._labeled_loader, self._unlabeled_loader = labeled_loader, unlabeled_loader
+        self._sup_criterion = sup_criterion
+        self._reg_weight = reg_weight
+        self._affine_transformer = TensorRandomFlip(axis=[1, 2], threshold=0.8)
+        assert isinstance(feature_position, list) and isinstance(feature_position[0], str), feature_position
+        assert isinstance(feature_importance, list) and isinstance(feature_importance[0], (int, float)), feature_importance
+        self._feature_position, self._feature_importance = feature_position, feature_importance
+        self._reducer = None  # set by miseg_amd.ddp.attach() for data-parallel runs
+
+    def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters.register_meter("lr", AverageValueMeter())
+        meters.register_meter("sup_loss", AverageValueMeter())
+        meters.register_meter("reg_loss", AverageValueMeter())
+        meters.register_meter("sup_dice", UniversalDice(self.num_classes, report_axises=list(range(1, self.num_classes))))
+        return meters
+
+    # ---- one optimisation step; returns nothing, leaves device scalars in self._pending
+    def _step(self, labeled_data, unlabeled_data):
+        seed = random.randint(0, int(1e7))
+        labeled_image, labeled_target, _, _, label_group = self._unzip_data(labeled_data, self._device)
+        unlabeled_image, _unlabeled_target, *_ = self._unzip_data(unlabeled_data, self._device)
+        lb, ub = len(labeled_image), len(unlabeled_image)
+        with FixRandomSeed(seed):  # same draws, same order as the per-sample flips at ref :148-149
+            decisions = self._affine_transformer.decisions(ub)
+        flips = ops.flips_to_tensor(decisions, labeled_image.device)
+        unlabeled_image_tf = ops.flip(unlabeled_image, flips)
+        assert unlabeled_image_tf.shape == unlabeled_image.shape
+
+        predict_logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
+        label_logits, unlabel_logits, unlabel_tf_logits = torch.split(predict_logits, [lb, ub, ub], dim=0)
+        labels = labeled_target.squeeze(1)
+        if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
+            sup_loss = self._sup_criterion.from_logits(label_logits, labels)
+        else:
+            sup_loss = self._sup_criterion(label_logits.softmax(1), class2one_hot(labels, self.num_classes))
+        reg_fn = self.regularization
+        fused = getattr(reg_fn, "_miseg_fused", False)
+        reg_loss = reg_fn(
+            unlabeled_tf_logits=unlabel_tf_logits,
+            unlabeled_logits_tf=None if fused else ops.flip(unlabel_logits, flips),
+            seed=seed, unlabeled_image=unlabeled_image, unlabeled_image_tf=unlabeled_image_tf,
+            unlabeled_logits=unlabel_logits, flips=flips, num_unlabeled=ub,
+        )
+        total_loss = sup_loss + self._reg_weight * reg_loss
+        self._optimizer.zero_grad()
+        if self._reducer is not None:
+            self._reducer.prepare()
+        total_loss.backward()
+        if self._reducer is not None:
+            self._reducer.finish()
+        self._optimizer.step()
+        with torch.no_grad():
+            self._pending.put("sup_loss", sup_loss)
+            self._pending.put("reg_loss", reg_loss)
+            _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False)
+        return inter, union, label_group
+
+    def _run(self, *args, **kwargs) -> EpochResultDict:
+        self.meters["lr"].add(get_lrs_from_optimizer(self._optimizer)[0])
+        self._model.train()
+        assert self._model.training, self._model.training
+        report_dict = {}
+        self._pending = _Pending()
+        with FeatureExtractor(self._model, self._feature_position) as self._fextractor:
+            for _, labeled_data, unlabeled_data in zip(self._indicator, self._labeled_loader, self._unlabeled_loader):
+                inter, union, label_group = self._step(labeled_data, unlabeled_data)
+                self._record(self._pending.fetch(), inter, union, label_group)  # the iteration's single host sync
+                report_dict = self.meters.tracking_status()
+                self._indicator.set_postfix_dict(report_dict)
+        return report_dict
+
+    def _record(self, host: dict, inter: Tensor, union: Tensor, label_group) -> None:
+        self.meters["sup_loss"].add(host["sup_loss"])
+        self.meters["sup_dice"].add_counts(inter, union, group_name=label_group)
+        self.meters["reg_loss"].add(host["reg_loss"])
+
+    @staticmethod
+    def _unzip_data(data, device):
+        (image, target), _, filename, partition, group = preprocess_input_with_twice_transformation(data, device)
+        return image, target, filename, partition, group
+
+    @_fused
+    def regularization(self, *args, **kwargs):
+        return torch.zeros((), dtype=torch.float, device=self._device)
+
+
+class UDATrainEpocher(TrainEpocher):
+    """Consistency between f(flip(x)) and flip(f(x)).detach() (ref :200-226)."""
+
+    def __init__(self, model, optimizer, labeled_loader, unlabeled_loader, sup_criterion, reg_criterion: T_loss, reg_weight: float,
+                 num_batches: int, cur_epoch: int = 0, device="cpu", feature_position=None, feature_importance=None) -> None:
+        super().__init__(model, optimizer, labeled_loader, unlabeled_loader, sup_criterion, reg_weight, num_batches, cur_epoch,
+                         device, feature_position, feature_importance)
+        self._reg_criterion = reg_criterion
+
+    def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters = super()._configure_meters(meters)
+        meters.register_meter("uda", AverageValueMeter())
+        return meters
+
+    def _uda(self, unlabeled_tf_logits: Tensor, unlabeled_logits: Tensor, flips: Tensor) -> Tensor:
+        if isinstance(self._reg_criterion, nn.MSELoss):
+            loss = ops.softmax_mse(unlabeled_tf_logits, unlabeled_logits, flips)  # flip + 2 softmaxes + MSE fused
+        else:  # e.g. the KL variant (ref trainer.py:137): generic criterion on materialised operands
+            loss = self._reg_criterion(unlabeled_tf_logits.softmax(1), ops.flip(unlabeled_logits, flips).softmax(1).detach())
+        self._pending.put("uda", loss)
+        return loss
+
+    @_fused
+    def regularization(self, unlabeled_tf_logits: Tensor, unlabeled_logits_tf: Tensor = None, seed=None, *args,
+                       unlabeled_logits: Tensor = None, flips: Tensor = None, **kwargs):
+        return self._uda(unlabeled_tf_logits, unlabeled_logits, flips)
+
+    def _record(self, host, inter, union, label_group):
+        super()._record(host, inter, union, label_group)
+        if "uda" in host:
+            self.meters["uda"].add(host["uda"])
+
+
+class IICTrainEpocher(TrainEpocher):
+    """Global (encoder taps) + local (decoder taps) IIC mutual information (ref :229-284)."""
+
+    def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters = super()._configure_meters(meters)
+        meters.register_meter("mi", AverageValueMeter())
+        meters.register_meter("individual_mis", MultipleAverageValueMeter())
+        return meters
+
+    def __init__(self, model, projectors_wrapper: ProjectorWrapper, optimizer, labeled_loader, unlabeled_loader, sup_criterion,
+                 IIDSegCriterionWrapper: IICLossWrapper, reg_weight: float, num_batches: int, cur_epoch: int = 0, device="cpu",
+                 feature_position=None, feature_importance=None) -> None:
+        super().__init__(model, optimizer, labeled_loader, unlabeled_loader, sup_criterion, reg_weight, num_batches, cur_epoch,
+                         device, feature_position, feature_importance)
+        assert projectors_wrapper.feature_names == self._feature_position
+        self._projectors_wrapper = projectors_wrapper
+        assert IIDSegCriterionWrapper.feature_names == self._feature_position
+        self._IIDSegCriterionWrapper = IIDSegCriterionWrapper
+
+    def _iic(self, flips: Tensor, ub: int) -> Tensor:
+        dev = flips.device
+        no_flip = torch.zeros_like(flips)
+        losses = []
+        for feature, projector, criterion in zip(self._fextractor, self._projectors_wrapper, self._IIDSegCriterionWrapper):
+            total = feature.shape[0]
+            # last 2*UB samples of the tap: [features(unlabeled) | features(flip(unlabeled))]   (ref :258-259)
+            src = torch.arange(total - 2 * ub, total, dtype=torch.int32, device=dev)
+            if isinstance(projector, ClusterHead):  # encoder tap: global pooling is flip-invariant (ref :261-262)
+                probs = projector.forward_gathered(feature, src)                       # [S, 2UB, K]
+                if _DEBUG_ASSERTS:
+                    from contrastyou.losses.iic_loss import simplex
+                    assert simplex(probs.flatten(0, 1))
+                per_head, _, _ = ops.global_mi(probs[:, :ub], probs[:, ub:], criterion.lamb)
+                losses.append(per_head.mean())
+            else:  # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
+                probs = projector.forward_gathered(feature, src, torch.cat([flips, no_flip]))  # [S, 2UB, K, H, W]
+                per_head = [criterion(p[:ub], p[ub:]) for p in probs]
+                losses.append(average_iter(per_head))
+        reg_loss = weighted_average_iter(losses, self._feature_importance)
+        self._pending.put("mi", -reg_loss)
+        for name, v in zip(self._feature_position, losses):
+            self._pending.put("mi/" + name, -v)
+        return reg_loss
+
+    @_fused
+    def regularization(self, unlabeled_tf_logits: Tensor, unlabeled_logits_tf: Tensor = None, seed: int = None, *args,
+                       flips: Tensor = None, num_unlabeled: int = None, **kwargs):
+        return self._iic(flips, num_unlabeled if num_unlabeled is not None else len(unlabeled_tf_logits))
+
+    def _record(self, host, inter, union, label_group):
+        super()._record(host, inter, union, label_group)
+        if "mi" in host:
+            self.meters["mi"].add(host["mi"])
+            self.meters["individual_mis"].add(**{n: host["mi/" + n] for n in self._feature_position})
+
+
+class UDAIICEpocher(IICTrainEpocher):
+    """``cons_weight * UDA + iic_weight * IIC`` with reg_weight forced to 1 (ref :287-323)."""
+
+    def __init__(self, model, projectors_wrapper: ProjectorWrapper, optimizer, labeled_loader, unlabeled_loader, sup_criterion,
+                 reg_criterion: T_loss, IIDSegCriterion: T_loss, num_batches: int, cur_epoch: int = 0, device="cpu",
+                 feature_position=None, feature_importance=None, cons_weight=1, iic_weight=0.1) -> None:
+        super().__init__(model, projectors_wrapper, optimizer, labeled_loader, unlabeled_loader, sup_criterion, IIDSegCriterion,
+                         1.0, num_batches, cur_epoch, device, feature_position, feature_importance)
+        self._cons_weight, self._iic_weight = cons_weight, iic_weight
+        self._reg_criterion = reg_criterion
+
+    def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters = super()._configure_meters(meters)
+        for name in ("uda", "iic_weight", "uda_weight"):
+            meters.register_meter(name, AverageValueMeter())
+        return meters
+
+    _uda = UDATrainEpocher._uda
+
+    @_fused
+    def regularization(self, unlabeled_tf_logits: Tensor, unlabeled_logits_tf: Tensor = None, seed: int = None, *args,
+                       unlabeled_logits: Tensor = None, flips: Tensor = None, num_unlabeled: int = None, **kwargs):
+        self.meters["iic_weight"].add(self._iic_weight)
+        self.meters["uda_weight"].add(self._cons_weight)
+        iic_loss = self._iic(flips, num_unlabeled if num_unlabeled is not None else len(unlabeled_tf_logits))
+        cons_loss = self._uda(unlabeled_tf_logits, unlabeled_logits, flips)
+        return self._cons_weight * cons_loss + self._iic_weight * iic_loss
+
+    def _record(self, host, inter, union, label_group):
+        super()._record(host, inter, union, label_group)
+        self.meters["uda"].add(host["uda"])

@@ -1,0 +1,44 @@
+"""Entry point with the reference's surface: ``python semi_seg/main.py Trainer.name=udaiic key=value ...``
+(ref: semi_seg/main.py:1-45).  The ACDC PNG pipeline (ref semi_seg/dataloader_helper.py) is outside the hot-path
+scope; ``Data.name=synthetic`` (default when ACDC is absent) feeds ACDC-shaped synthetic slices."""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+from contrastyou import PROJECT_PATH  # noqa: E402
+from contrastyou.arch import UNet  # noqa: E402
+from deepclustering2.configparser import ConfigManger  # noqa: E402
+from deepclustering2.loss import KL_div  # noqa: E402
+from deepclustering2.utils import gethash, set_benchmark  # noqa: E402
+from semi_seg.synthetic import SyntheticEval, SyntheticPairs  # noqa: E402
+from semi_seg.trainer import trainer_zoos  # noqa: E402
+
+
+def main(argv=None):
+    cmanager = ConfigManger(Path(PROJECT_PATH) / "config/semi.yaml", argv=argv)
+    config = cmanager.config
+    set_benchmark(config.get("RandomSeed", 1))
+    size = int(config.get("Data", {}).get("size", 256))
+    classes = config["Arch"]["num_classes"]
+    rank = int(os.environ.get("RANK", 0))
+    labeled_loader = SyntheticPairs(config["LabeledData"]["batch_size"], size, classes, seed=2 * rank)
+    unlabeled_loader = SyntheticPairs(config["UnlabeledData"]["batch_size"], size, classes, seed=2 * rank + 1)
+    val_loader, test_loader = SyntheticEval(2, 4, size, classes, seed=100), SyntheticEval(2, 4, size, classes, seed=101)
+    trainer_name = config["Trainer"].pop("name")
+    model = UNet(**config["Arch"])
+    trainer = trainer_zoos[trainer_name](
+        model=model, labeled_loader=iter(labeled_loader), unlabeled_loader=iter(unlabeled_loader), val_loader=val_loader,
+        test_loader=test_loader, sup_criterion=KL_div(), configuration={**cmanager.config, **{"GITHASH": gethash(__file__)}},
+        **config["Trainer"])
+    trainer.init()
+    checkpoint = config.get("Checkpoint", None)
+    if checkpoint is not None:
+        trainer.load_state_dict_from_path(checkpoint, strict=False)
+    trainer.start_training()
+    return trainer
+
+
+if __name__ == "__main__":
+    main()

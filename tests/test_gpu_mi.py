@@ -1,0 +1,183 @@
+"""GPU parity: local / global IIC mutual information and the cluster heads (HIP, through the C ABI)
+against the CPU oracle and the golden vectors generated from the reference.
+
+Tolerance policy (stated once): the MI loss is a small difference of O(1) entropies, so two correct
+fp32 evaluations with different summation order differ by ~1e-7 absolute -- not 1e-5 relative to a
+loss that can itself be 1e-6.  We therefore require
+  * the raw displacement joint (the contraction): 1e-5 relative to its largest entry;
+  * the loss: |hip - truth| <= 1e-5 * (sum of |summands|) where truth is the fp64 oracle, i.e. 1e-5
+    relative to the entropy scale, AND no worse than 4x the reference's own fp32 deviation + 1e-7;
+  * gradients: 1e-4 of the gradient scale vs the fp64 oracle (fp32 reference itself is at that level).
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import heads as OH
+from oracle import iic as OI
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda"
+
+LOCAL_CASES = [(3, 5, 12, 10, 2), (4, 20, 32, 32, 1), (4, 20, 32, 32, 3), (2, 8, 64, 64, 3)]
+
+
+def ops():
+    from miseg_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("n,k,h,w,p", LOCAL_CASES)
+def test_local_joint_and_loss_vs_golden(golden, n, k, h, w, p):
+    g = golden("iic")
+    key = f"local_f32_n{n}_k{k}_h{h}_w{w}_p{p}"
+    x = T(synth.probs(key + "/x", (n, k, h, w))).to(DEV).requires_grad_(True)
+    y = T(synth.probs(key + "/y", (n, k, h, w))).to(DEV).requires_grad_(True)
+    win = [(0, h, 0, w)]
+    raw = ops().local_mi_raw_joint(x.detach(), y.detach(), p, win)[0].cpu().numpy()        # [T,T,K,K]
+    ref_raw = np.transpose(g[f"{key}/raw_kktt"], (2, 3, 0, 1))
+    np.testing.assert_allclose(raw, ref_raw, rtol=1e-5, atol=1e-5 * np.abs(ref_raw).max())
+    loss = ops().local_mi_losses(x, y, p, win)[0]
+    # fp64 truth on the same fp32 inputs
+    x64, y64 = x.detach().cpu().double().requires_grad_(True), y.detach().cpu().double().requires_grad_(True)
+    truth = OI.iid_seg_loss(x64, y64, p)
+    gx64, gy64 = torch.autograd.grad(truth, [x64, y64])
+    ref_dev = abs(float(g[f"{key}/loss"]) - float(truth))
+    assert abs(float(loss) - float(truth)) <= 4 * ref_dev + 1e-7, (float(loss), float(truth), ref_dev)
+    loss.backward()
+    gscale = float(gx64.abs().max())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gx64.numpy(), rtol=0, atol=1e-4 * gscale + 1e-12)
+    np.testing.assert_allclose(y.grad.cpu().numpy(), gy64.numpy(), rtol=0, atol=1e-4 * gscale + 1e-12)
+
+
+@pytest.mark.parametrize("n,k,h,w,p,patch,use_mask", [(2, 4, 100, 100, 1, 32, False), (2, 4, 100, 100, 1, 32, True),
+                                                       (2, 6, 64, 64, 2, 1024, False), (2, 5, 48, 40, 1, 16, True)])
+def test_patch_local_mi(golden, n, k, h, w, p, patch, use_mask):
+    """Overlapping patch windows (incl. the clamped last window) + optional mask, one batched launch."""
+    key = f"patch_f64_n{n}_k{k}_h{h}_w{w}_p{p}_ps{patch}_m{int(use_mask)}"
+    x64 = T(synth.probs(key + "/x", (n, k, h, w), np.float64)).float().double().requires_grad_(True)
+    y64 = T(synth.probs(key + "/y", (n, k, h, w), np.float64)).float().double().requires_grad_(True)
+    m = T(synth.mask(key + "/mask", (n, 1, h, w))) if use_mask else None
+    truth = OI.iid_seg_small_patch_loss(x64, y64, p, patch, mask=None if m is None else m.double())
+    gx64, gy64 = torch.autograd.grad(truth, [x64, y64])
+    x = x64.detach().float().to(DEV).requires_grad_(True)
+    y = y64.detach().float().to(DEV).requires_grad_(True)
+    wins = OI.patch_windows(h, w, (patch, patch), (patch // 2, patch // 2))
+    losses = ops().local_mi_losses(x, y, p, wins, mask=None if m is None else m.to(DEV))
+    loss = losses.sum() / float(len(wins))
+    assert abs(float(loss) - float(truth)) <= 2e-6, (float(loss), float(truth))
+    loss.backward()
+    gscale = float(gx64.abs().max())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gx64.numpy(), rtol=0, atol=2e-3 * gscale + 1e-12)
+    np.testing.assert_allclose(y.grad.cpu().numpy(), gy64.numpy(), rtol=0, atol=2e-3 * gscale + 1e-12)
+
+
+def test_local_mi_full_size_properties():
+    """BASELINE cfg2 shape (16x20x256x256, pad 3): size-independent properties instead of a CPU oracle run:
+    (1) sum_{i,j} R[a,b,i,j] == number of valid (pixel, displacement) pairs * N  (both inputs are simplexes);
+    (2) swapping x<->y transposes (i,j) and mirrors the displacement; (3) joint is linear in x."""
+    n, k, h, w, p = 16, 20, 256, 256, 3
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(n, k, h, w, generator=gen).softmax(1).to(DEV)
+    y = torch.randn(n, k, h, w, generator=gen).softmax(1).to(DEV)
+    win = [(0, h, 0, w)]
+    raw = ops().local_mi_raw_joint(x, y, p, win)[0]
+    t = 2 * p + 1
+    counts = torch.empty(t, t)
+    for a in range(t):
+        for b in range(t):
+            counts[a, b] = (h - abs(a - p)) * (w - abs(b - p)) * n
+    np.testing.assert_allclose(raw.sum(dim=(2, 3)).cpu().numpy(), counts.numpy(), rtol=2e-5)
+    raw_sw = ops().local_mi_raw_joint(y, x, p, win)[0]
+    np.testing.assert_allclose(raw_sw.cpu().numpy(), raw.flip(0, 1).transpose(2, 3).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    raw2 = ops().local_mi_raw_joint(0.5 * x, y, p, win)[0]
+    np.testing.assert_allclose(raw2.cpu().numpy(), 0.5 * raw.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,k", [(7, 5), (16, 20)])
+def test_global_mi(golden, n, k):
+    g = golden("iic")
+    key = f"global_f32_n{n}_k{k}"
+    x = T(synth.probs(key + "/x", (n, k))).to(DEV)
+    y = T(synth.probs(key + "/y", (n, k))).to(DEV)
+    xs = torch.stack([x, y, x]).requires_grad_(True)    # three "sub-heads" in one launch
+    ys = torch.stack([y, x, x]).requires_grad_(True)
+    loss, loss_nl, joint = ops().global_mi(xs, ys)
+    np.testing.assert_allclose(joint[0].detach().cpu().numpy(), g[f"{key}/joint"], rtol=1e-5, atol=1e-8)
+    x64, y64 = x.cpu().double().requires_grad_(True), y.cpu().double().requires_grad_(True)
+    truth, truth_nl, _ = OI.iid_loss(x64, y64)
+    ref_dev = abs(float(g[f"{key}/loss"]) - float(truth))
+    assert abs(float(loss[0]) - float(truth)) <= 4 * ref_dev + 2e-7
+    assert abs(float(loss_nl[0]) - float(truth_nl)) <= 4 * ref_dev + 2e-7
+    gx64, gy64 = torch.autograd.grad(truth, [x64, y64])
+    loss[0].backward()
+    gscale = float(gx64.abs().max())
+    np.testing.assert_allclose(xs.grad[0].cpu().numpy(), gx64.numpy(), rtol=0, atol=2e-4 * gscale + 1e-9)
+    np.testing.assert_allclose(ys.grad[0].cpu().numpy(), gy64.numpy(), rtol=0, atol=2e-4 * gscale + 1e-9)
+    assert float(xs.grad[1].abs().max()) == 0.0   # untouched sub-heads get exactly zero
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_local_head_fwd_bwd(golden, dtype):
+    """LocalClusterHead (linear) incl. the fused sample gather + flip replay, vs oracle autograd."""
+    g = golden("heads")
+    sd = OH.init_local_cluster_head(8, 6, 3, "linear", seed=6)
+    feat = T(synth.normal("dec_linear_norm0/feat", (3, 8, 10, 12)))
+    w = torch.stack([sd[f"_headers.{s}.0.weight"].view(6, 8) for s in range(3)])
+    b = torch.stack([sd[f"_headers.{s}.0.bias"] for s in range(3)])
+    src = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    fd = feat.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    prob = ops().local_head(fd, wd, bd, src, None)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    if dtype == torch.float32:
+        for s in range(3):
+            np.testing.assert_allclose(prob[s].detach().cpu().numpy(), g[f"dec_linear_norm0/out{s}"], **tol)
+    # gather + flips + backward against the oracle on the (dtype-rounded) feature
+    f_ref = fd.detach().float().cpu().contiguous().requires_grad_(True)
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    order, dec = [2, 0, 1], [[True, False], [False, True], [True, True]]   # sources must be distinct (gfeat scatter)
+    gathered = torch.stack([f_ref[i] for i in order])
+    from oracle import losses as OL
+    ref_probs = OH.local_cluster_head(sd_ref, OL.apply_flips(gathered, dec))
+    cot = T(synth.normal("head/cot", (3, 3, 6, 10, 12)))
+    sum((p * c).sum() for p, c in zip(ref_probs, cot)).backward()
+    src2 = torch.tensor(order, dtype=torch.int32, device=DEV)
+    flips = ops().flips_to_tensor(dec, DEV)
+    prob2 = ops().local_head(fd, wd, bd, src2, flips)
+    for s in range(3):
+        np.testing.assert_allclose(prob2[s].detach().cpu().numpy(), ref_probs[s].detach().numpy(), **tol)
+    (prob2 * cot.to(DEV)).sum().backward()
+    gw_ref = torch.stack([sd_ref[f"_headers.{s}.0.weight"].grad.view(6, 8) for s in range(3)])
+    gb_ref = torch.stack([sd_ref[f"_headers.{s}.0.bias"].grad for s in range(3)])
+    gt = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), gw_ref.numpy(), **gt)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), gb_ref.numpy(), **gt)
+    np.testing.assert_allclose(fd.grad.float().cpu().numpy(), f_ref.grad.numpy(), **gt)
+
+
+def test_global_head_fwd_bwd(golden):
+    g = golden("heads")
+    sd = OH.init_cluster_head(32, 6, 3, "linear", seed=5)
+    feat = T(synth.normal("enc_linear_norm0/feat", (5, 32, 6, 6)))
+    w = torch.stack([sd[f"_headers.{s}.2.weight"] for s in range(3)])
+    b = torch.stack([sd[f"_headers.{s}.2.bias"] for s in range(3)])
+    src = torch.arange(5, dtype=torch.int32, device=DEV)
+    fd = feat.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    prob = ops().global_head(fd, wd, bd, src)
+    for s in range(3):
+        np.testing.assert_allclose(prob[s].detach().cpu().numpy(), g[f"enc_linear_norm0/out{s}"], rtol=1e-5, atol=1e-7)
+    f_ref = feat.clone().requires_grad_(True)
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = OH.cluster_head(sd_ref, f_ref)
+    cot = T(synth.normal("ghead/cot", (3, 5, 6)))
+    sum((p * c).sum() for p, c in zip(ref, cot)).backward()
+    (prob * cot.to(DEV)).sum().backward()
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), torch.stack([sd_ref[f"_headers.{s}.2.weight"].grad for s in range(3)]).numpy(),
+                               rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), torch.stack([sd_ref[f"_headers.{s}.2.bias"].grad for s in range(3)]).numpy(),
+                               rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(fd.grad.cpu().numpy(), f_ref.grad.numpy(), rtol=1e-4, atol=1e-7)
