@@ -74,9 +74,42 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
-def call(name: str, *args) -> None:
+class KernelTimer:
+    """Optional per-entry-point device timing with HIP events on the launching stream (bench.py roofline).
+    ``work`` = algorithmic (flops, bytes) of the call, supplied by the caller of ``call``."""
+
+    def __init__(self):
+        self.records = {}  # name -> [ [start_event, end_event], flops, bytes ]
+
+    def wrap(self, name, work, fn):
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.setdefault(name, []).append((s, e, work[0], work[1]))
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[name] = {"calls": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                         "flops_per_call": sum(r[2] for r in recs) / len(recs), "bytes_per_call": sum(r[3] for r in recs) / len(recs)}
+        return out
+
+
+TIMER = None  # set to a KernelTimer by bench.py
+
+
+def call(name: str, *args, work=None, tag=None) -> None:
     """Invoke an int-returning entry point and turn a negative status into an exception."""
-    rc = getattr(lib(), name)(*args)
+    fn = getattr(lib(), name)
+    if TIMER is not None and work is not None:
+        box = []
+        TIMER.wrap(tag or name, work, lambda: box.append(fn(*args)))
+        rc = box[0]
+    else:
+        rc = fn(*args)
     if rc != 0:
         msg = lib().miseg_last_error()
         raise MisegError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")

@@ -70,8 +70,9 @@ class _LocalMI(torch.autograd.Function):
         t = 2 * pad + 1
         raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), dev)
+        px = sum((a1 - a0) * (b1 - b0) for a0, a1, b0, b1 in windows)
         call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
-             _ptr(ws), ws.numel())
+             _ptr(ws), ws.numel(), work=(2.0 * k * k * t * t * n * px, 2.0 * n * k * px * 4), tag=f"iic_local_joint_fwd[p{pad}]")
         loss = torch.empty(p, dtype=torch.float32, device=dev)
         grad_raw = torch.empty_like(raw)
         call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
@@ -92,8 +93,11 @@ class _LocalMI(torch.autograd.Function):
             else:
                 idx = torch.tensor(grp, dtype=torch.long, device=x.device)
                 gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[idx].contiguous(), scale[idx].contiguous()
+            px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
+            tt = (2 * ctx.pad + 1) ** 2
             call("miseg_iic_local_bwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, ctx.pad, _ptr(gwin), len(grp),
-                 _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy))
+                 _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy), work=(4.0 * k * k * tt * n * px, 4.0 * n * k * px * 4),
+                 tag=f"iic_local_bwd[p{ctx.pad}]")
         return gx, gy, None, None, None, None
 
 
@@ -177,7 +181,8 @@ class _LocalHead(torch.autograd.Function):
         w, b = w.contiguous().float(), b.contiguous().float()
         prob = torch.empty(s, m, k, h, wd, dtype=torch.float32, device=feat.device)
         call("miseg_head_local_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), _ptr(b),
-             s, k, float(temperature), _ptr(prob))
+             s, k, float(temperature), _ptr(prob), work=(2.0 * s * k * c * m * h * wd, (s * k * 4.0 + c * feat.element_size()) * m * h * wd),
+             tag=f"head_local_fwd[c{c}]")
         ctx.save_for_backward(feat, w, src, flips, prob)
         ctx.temperature = float(temperature)
         return prob
@@ -194,7 +199,8 @@ class _LocalHead(torch.autograd.Function):
         gb = torch.empty(s, k, dtype=torch.float32, device=feat.device)
         ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
         call("miseg_head_local_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
-             ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel())
+             ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
+             work=(4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 2 * c * feat.element_size()) * m * h * wd), tag=f"head_local_bwd[c{c}]")
         return gfeat, gw, gb, None, None, None
 
 

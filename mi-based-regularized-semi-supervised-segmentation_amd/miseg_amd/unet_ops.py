@@ -67,8 +67,10 @@ class _ConvBNReLU(torch.autograd.Function):
             stats = torch.empty(parts * 2 * cout, dtype=torch.float32, device=dev)
         else:
             parts, stats = 0, None
+        es = x0.element_size()
         call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
-             _ptr(stats))
+             _ptr(stats), work=(18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout)),
+             tag="conv3x3_fwd")
         if training:
             call("miseg_bn_finalize", _stream(), _ptr(stats), parts, cout, n * h * w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved))
@@ -103,14 +105,16 @@ class _ConvBNReLU(torch.autograd.Function):
             gw = torch.empty_like(weight)
             ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
             call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
-                 _ptr(ws2), ws2.numel())
+                 _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
+                 tag="conv3x3_wgrad")
         grads = [None, None]
         for s, (cb, cs, ups, xs) in enumerate(((0, c0, ups0, x0), (c0, c1, ups1, x1))):
             if xs is None or not ctx.needs_input_grad[s]:
                 continue
             packed = _pack(weight, dtype, 1, cb, cs)
             gfull = empty_nhwc(n, cs, h, w, dtype, dev)
-            call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(graw), cout, 0, None, 0, 0, n, h, w, _ptr(packed), cs, _ptr(gfull), None)
+            call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(graw), cout, 0, None, 0, 0, n, h, w, _ptr(packed), cs, _ptr(gfull), None,
+                 work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs + cout)), tag="conv3x3_dgrad")
             if ups:
                 glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
                 call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)

@@ -113,3 +113,36 @@ def unet_forward(sd, x: Tensor, training: bool = True, update_stats: bool = True
 def trainable_keys(sd) -> list[str]:
     return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var")
                                   or k.endswith("num_batches_tracked"))]
+
+
+def unet_forward_bf16_emulated(sd, x: Tensor):
+    """Training-mode forward with the bf16 kernels' rounding points reproduced in fp32 arithmetic: operands
+    (activations, weights) rounded to bf16, fp32 accumulation, batch statistics from the un-rounded fp32
+    accumulators, the raw conv output and every stored activation rounded to bf16, logits fp32.  Used to check
+    the bf16 HIP path against 'the same computation' rather than against fp32 (random-init nets amplify bf16
+    rounding by a lot).  No buffers are updated."""
+    def r(t):
+        return t.bfloat16().float()
+
+    def cbr(t, ck, bk):
+        acc = F.conv2d(r(t), r(sd[f"{ck}.weight"]), None, 1, 1)
+        mean = acc.mean((0, 2, 3), keepdim=True)
+        var = acc.var((0, 2, 3), unbiased=False, keepdim=True)
+        invstd = torch.rsqrt(var + BN_EPS)
+        scale = sd[f"{bk}.weight"].view(1, -1, 1, 1) * invstd
+        shift = sd[f"{bk}.bias"].view(1, -1, 1, 1) - mean * scale
+        return r(F.relu(r(acc) * scale + shift))
+
+    def block(name, t):
+        return cbr(cbr(t, f"{name}.conv.0", f"{name}.conv.1"), f"{name}.conv.3", f"{name}.conv.4")
+
+    pool = lambda t: F.max_pool2d(t, 2, 2)  # noqa: E731
+    e1 = block("Conv1", x)
+    e2 = block("Conv2", pool(e1))
+    e3 = block("Conv3", pool(e2))
+    e4 = block("Conv4", pool(e3))
+    d = block("Conv5", pool(e4))
+    for lvl, skip in ((5, e4), (4, e3), (3, e2), (2, e1)):
+        u = cbr(F.interpolate(d, scale_factor=2, mode="nearest"), f"Up{lvl}.up.1", f"Up{lvl}.up.2")
+        d = block(f"Up_conv{lvl}", torch.cat((skip, u), 1))
+    return F.conv2d(d, sd["DeConv_1x1.weight"], sd["DeConv_1x1.bias"])

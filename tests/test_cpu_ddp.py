@@ -1,0 +1,71 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient reducer (miseg_amd.ddp.GradReducer) -- bucketed async
+all-reduce of the flat gradient launched from autograd hooks -- equals a single-process run on the
+concatenated batch shards (mean of per-rank gradients), including a parameter that gets no gradient."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "mi-based-regularized-semi-supervised-segmentation_amd")
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                               torch.nn.Linear(16, 3), torch.nn.Linear(3, 3))  # the last layer is never used -> no grad
+
+
+def _loss(model, x, y):
+    h = model[4](model[3](model[2](model[1](model[0](x)))))
+    return ((h - y) ** 2).mean()
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, SRC)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from miseg_amd import ddp
+    from miseg_amd.flat import FlatBuffers
+    assert ddp.init_from_env("gloo")
+    model = _model()
+    if rank == 1:  # de-synchronise on purpose: the reducer must broadcast rank 0's parameters
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    flat = FlatBuffers(list(model.parameters()))
+    red = ddp.GradReducer(flat, num_buckets=3)
+    assert len(red.buckets) >= 2 and red.buckets[0][3] == flat.total and red.buckets[-1][2] == 0
+    g = torch.Generator().manual_seed(100 + rank)
+    x, y = torch.randn(5, 6, generator=g), torch.randn(5, 3, generator=g)
+    for _ in range(2):  # two steps: state resets correctly
+        flat.zero_grad()
+        red.prepare()
+        _loss(model, x, y).backward()
+        red.finish()
+    torch.save({"grad": flat.flat_grad.clone(), "param": flat.flat_param.clone()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_matches_single_process(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{r}.pt") for r in range(world))
+    torch.testing.assert_close(r0["grad"], r1["grad"], rtol=0, atol=0)       # identical on every rank
+    torch.testing.assert_close(r0["param"], r1["param"], rtol=0, atol=0)     # broadcast from rank 0
+    # single-process reference: mean over ranks of the per-rank gradients
+    sys.path.insert(0, SRC)
+    from miseg_amd.flat import FlatBuffers
+    grads = []
+    for rank in range(world):
+        model = _model()
+        flat = FlatBuffers(list(model.parameters()))
+        flat.zero_grad()
+        g = torch.Generator().manual_seed(100 + rank)
+        x, y = torch.randn(5, 6, generator=g), torch.randn(5, 3, generator=g)
+        _loss(model, x, y).backward()
+        grads.append(flat.flat_grad.clone())
+    torch.testing.assert_close(r0["grad"], (grads[0] + grads[1]) / 2, rtol=1e-6, atol=1e-7)
+    assert float(r0["grad"][-12:].abs().max()) == 0.0   # the unused layer's slot stays exactly zero

@@ -1,0 +1,98 @@
+"""GPU parity of the WHOLE train step through the reference-compatible surface: my UDAIICEpocher / TrainEpocher
+(HIP kernels, exact-fp32 mode) vs the meters, gradients and updated weights the reference's own epochers produced
+on the same synthetic state and batches (tests/golden/step.npz)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import heads as OH
+from oracle import unet as OU
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda"
+STEP = dict(H=64, LB=2, UB=3, NB=2, lr=1e-3, wd=1e-5, cons_weight=5.0, iic_weight=0.1)
+FEATURES = ["Conv5", "Up_conv3", "Up_conv2"]
+
+
+def build(mode, dtype="float32"):
+    from contrastyou.arch import UNet
+    from deepclustering2.loss import KL_div
+    from deepclustering2.optim import Adam
+    from semi_seg._utils import IICLossWrapper, ProjectorWrapper
+    from itertools import chain
+    H, LB, UB, NB = (STEP[k] for k in ("H", "LB", "UB", "NB"))
+    model = UNet(1, 4, compute_dtype=dtype)
+    model.load_state_dict(OU.init_state(1, 4, seed=9))
+    pw = ProjectorWrapper()
+    pw.init_encoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
+    pw.init_decoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
+    pw._encoder_projectors["Conv5"].load_state_dict(OH.init_cluster_head(256, 20, 5, "linear", seed=10))
+    pw._decoder_projectors["Up_conv3"].load_state_dict(OH.init_local_cluster_head(32, 20, 5, "linear", seed=11))
+    pw._decoder_projectors["Up_conv2"].load_state_dict(OH.init_local_cluster_head(16, 20, 5, "linear", seed=12))
+    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=1024)
+    model, pw = model.to(DEV), pw.to(DEV)
+    params = chain(model.parameters(), pw.parameters()) if mode == "udaiic" else model.parameters()
+    opt = Adam(params, lr=STEP["lr"], weight_decay=STEP["wd"])
+
+    def loader(tag, B, with_tgt):
+        for i in range(NB):
+            img = T(synth.uniform(f"step/{mode}/{tag}{i}", (B, 1, H, H)))
+            tgt = T(synth.integers(f"step/{mode}/tgt{i}", (B, 1, H, H), 4)) if with_tgt else torch.zeros(B, 1, H, H, dtype=torch.long)
+            yield [[[img, tgt], [img.clone(), tgt.clone()]], [f"patient{j:03d}_00_{j}" for j in range(B)], ["0"] * B,
+                   [f"patient{j:03d}_00" for j in range(B)]]
+
+    return model, pw, lw, opt, loader("lab", LB, True), loader("unl", UB, False), KL_div(verbose=False)
+
+
+@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+def test_epocher_matches_reference_run(golden, mode):
+    from semi_seg.epocher import TrainEpocher, UDAIICEpocher
+    g = golden("step")
+    model, pw, lw, opt, lab, unl, kl = build(mode)
+    fi = [float(v) for v in g[f"{mode}/feature_importance"]]
+    random.seed(1234)
+    if mode == "udaiic":
+        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=STEP["NB"], cur_epoch=0, device=DEV,
+                           feature_position=FEATURES, feature_importance=fi, cons_weight=STEP["cons_weight"], iic_weight=STEP["iic_weight"])
+    else:
+        ep = TrainEpocher(model, opt, lab, unl, kl, 0, STEP["NB"], 0, DEV, feature_position=FEATURES, feature_importance=fi)
+    res = ep.run()
+    got = {f"{k}/{kk}": float(vv) for k, v in res.items() for kk, vv in dict(v).items()}
+    ref = dict(zip([str(k) for k in g[f"{mode}/meter_keys"]], g[f"{mode}/meter_values"]))
+    assert set(got) == set(ref), set(got) ^ set(ref)                      # identical meter names
+    np.testing.assert_allclose(got["lr/mean"], ref["lr/mean"], rtol=1e-12)
+    np.testing.assert_allclose(got["sup_loss/mean"], ref["sup_loss/mean"], rtol=2e-5)
+    for k in ("sup_dice/DSC1", "sup_dice/DSC2", "sup_dice/DSC3", "sup_dice/DSC_mean"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=2e-3)            # integer counts; an argmax tie can move a pixel
+    np.testing.assert_allclose(got["reg_loss/mean"], ref["reg_loss/mean"], rtol=2e-4, atol=1e-7)
+    if mode == "udaiic":
+        np.testing.assert_allclose(got["uda/mean"], ref["uda/mean"], rtol=2e-4)
+        for k in ("mi/mean", "individual_mis/Conv5", "individual_mis/Up_conv3", "individual_mis/Up_conv2"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=2e-3, atol=2e-6)  # MI of an untrained head: O(1e-3..1e-6), see test_gpu_mi
+        assert got["iic_weight/mean"] == ref["iic_weight/mean"] and got["uda_weight/mean"] == ref["uda_weight/mean"]
+    # weights after two Adam steps: every entry moved by at most ~lr per step; sign-noise gradients bound the deviation
+    for k, v in model.state_dict().items():
+        fp = synth.fp_unpack(g, f"{mode}/model_after/{k}")
+        synth.check_fingerprint(v.detach().float().cpu().numpy(), fp, f"{mode}/model_after/{k}", rtol=2e-3,
+                                atol=2.5 * STEP["lr"] * STEP["NB"])
+    moved = float((model.state_dict()["Conv1.conv.0.weight"].cpu() - OU.init_state(1, 4, seed=9)["Conv1.conv.0.weight"]).abs().mean())
+    assert 0.2 * STEP["lr"] < moved < 2.5 * STEP["lr"] * STEP["NB"], moved   # the optimiser really stepped
+
+
+def test_udaiic_step_bf16_runs_and_tracks_fp32(golden):
+    """bf16 compute mode (BASELINE cfg2 dtype): same step, losses within bf16 tolerance of the fp32 golden."""
+    from semi_seg.epocher import UDAIICEpocher
+    g = golden("step")
+    model, pw, lw, opt, lab, unl, kl = build("udaiic", "bfloat16")
+    fi = [float(v) for v in g["udaiic/feature_importance"]]
+    random.seed(1234)
+    res = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=STEP["NB"], cur_epoch=0, device=DEV,
+                        feature_position=FEATURES, feature_importance=fi, cons_weight=5.0, iic_weight=0.1).run()
+    ref = dict(zip([str(k) for k in g["udaiic/meter_keys"]], g["udaiic/meter_values"]))
+    np.testing.assert_allclose(res["sup_loss"]["mean"], ref["sup_loss/mean"], rtol=2e-2)
+    np.testing.assert_allclose(res["uda"]["mean"], ref["uda/mean"], rtol=0.25)
+    assert abs(res["mi"]["mean"] - ref["mi/mean"]) < 0.5 * abs(ref["mi/mean"]) + 1e-4
