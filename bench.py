@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Benchmark of the udaiic train step (BASELINE.json metric: images/sec, UNet+IIC fwd/bwd, ACDC 256^2).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full optimisation step of ``UDAIICEpocher`` (one U-Net forward on LB+2*UB slices, supervised KL,
+UDA MSE, global+local IIC on three taps x five sub-heads, one backward, fused Adam) on synthetic ACDC-shaped
+1x256x256 4-class slices -- BASELINE.json configs[1]: LB=UB=16 per GPU, bf16 compute.  ``value`` = unique loader
+slices (LB+UB per rank) per second, whole job.  Rank 0 prints ONE JSON line with, besides the contract fields,
+  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events on the launching stream, in the timed region)
+  cpu_baseline : the CPU oracle (a port of the reference algorithm) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(ROOT, "mi-based-regularized-semi-supervised-segmentation_amd")
+for p in (ROOT, SRC):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("MISEG_PROGRESS", "0")
+
+import torch  # noqa: E402
+
+FEATURES = ["Conv5", "Up_conv3", "Up_conv2"]
+PEAK = {"mfma_bf16": 2500.0, "mfma_f32": 157.3, "hbm": 8000.0}  # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
+
+
+def build_step(device, lb, ub, size, dtype, rank):
+    from itertools import chain
+
+    from contrastyou.arch import UNet
+    from deepclustering2.loss import KL_div
+    from deepclustering2.optim import Adam
+    from semi_seg._utils import IICLossWrapper, ProjectorWrapper
+    from semi_seg.epocher import UDAIICEpocher
+    from semi_seg.synthetic import SyntheticPairs
+    torch.manual_seed(0)  # identical initial weights on every rank
+    model = UNet(input_dim=1, num_classes=4, compute_dtype=dtype)
+    pw = ProjectorWrapper()
+    pw.init_encoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
+    pw.init_decoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
+    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=1024)
+    model, pw = model.to(device), pw.to(device)
+    opt = Adam(chain(model.parameters(), pw.parameters()), lr=1e-7 * 400, weight_decay=1e-5)
+    torch.manual_seed(rank), random.seed(rank)
+    lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=device)
+    unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=device)
+    ep = UDAIICEpocher(model, pw, opt, iter(lab), iter(unl), KL_div(verbose=False), torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0,
+                       device=device, feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1)
+    return ep, opt
+
+
+class StepDriver:
+    """Runs UDAIICEpocher steps exactly as ``_run`` does (same code path, incl. the per-iteration meter sync),
+    but under external timing."""
+
+    def __init__(self, ep):
+        from semi_seg._utils import FeatureExtractor
+        from semi_seg.epocher import _Pending
+        self.ep = ep
+        ep._model.train()
+        ep.meters = ep._configure_meters(__import__("deepclustering2.meters2", fromlist=["MeterInterface"]).MeterInterface())
+        ep._pending = _Pending()
+        self._fx = FeatureExtractor(ep._model, ep._feature_position)
+        ep._fextractor = self._fx.__enter__()
+
+    def step(self):
+        ep = self.ep
+        inter, union, grp = ep._step(next(ep._labeled_loader), next(ep._unlabeled_loader))
+        ep._record(ep._pending.fetch(), inter, union, grp)
+
+    def close(self):
+        self._fx.__exit__(None, None, None)
+
+
+def cpu_baseline(threads):
+    """The oracle (CPU port of the reference step) on a bounded sample: one udaiic step at LB=UB=2, 256x256, fp32."""
+    from oracle import heads as OH, step as OS, unet as OU
+    torch.set_num_threads(threads)
+    lb = ub = 2
+    g = torch.Generator().manual_seed(0)
+    state = OS.StepState(OU.init_state(1, 4, seed=1), {"Conv5": OH.init_cluster_head(256, 20, 5, seed=2),
+                                                        "Up_conv3": OH.init_local_cluster_head(32, 20, 5, seed=3),
+                                                        "Up_conv2": OH.init_local_cluster_head(16, 20, 5, seed=4)}, lr=4e-5, weight_decay=1e-5)
+    lab, tgt = torch.rand(lb, 1, 256, 256, generator=g), torch.randint(0, 4, (lb, 1, 256, 256), generator=g)
+    unl = torch.rand(ub, 1, 256, 256, generator=g)
+    t0 = time.time()
+    OS.train_step(state, lab, tgt, unl, seed=123, mode="udaiic")
+    dt = time.time() - t0
+    return {"value": round((lb + ub) / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 udaiic train step of the CPU oracle (oracle/step.py), LB=UB={lb}, 256x256, fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--lb", type=int, default=16)
+    ap.add_argument("--ub", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    from miseg_amd import _cabi, ddp
+    _cabi.lib()
+    distributed = ddp.init_from_env("nccl")
+
+    ep, opt = build_step(device, args.lb, args.ub, args.size, args.dtype, rank)
+    drv = StepDriver(ep)
+    if distributed:
+        opt.flat.ensure()
+        ep._reducer = ddp.GradReducer(opt.flat, num_buckets=3)
+
+    def barrier():
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"built step: world={world} LB=UB={args.lb} {args.size}x{args.size} {args.dtype}")
+    for i in range(args.warmup):
+        drv.step()
+        note(f"warmup step {i} done")
+    timer = None
+    if rank == 0 and not args.no_kernel_timer:
+        timer = _cabi.KernelTimer()
+        _cabi.TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    note(f"timed {args.steps} steps in {dt:.3f} s")
+    _cabi.TIMER = None
+    drv.close()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if distributed:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        images = (args.lb + args.ub) * world * args.steps
+        out = {
+            "metric": "images/sec (UNet+IIC fwd/bwd) ACDC 256^2", "value": round(images / dt, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
+                                   f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
+                       "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
+                       "parallelism": f"dp{world}"},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            table = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])
+            name, top = table[0]
+            mfma_f32 = name.startswith(("iic_local", "conv3x3_wgrad", "head_local_bwd")) or args.dtype == "float32"
+            tf = top["flops_per_call"] / (top["avg_ms"] * 1e-3) / 1e12
+            peak = PEAK["mfma_f32"] if mfma_f32 else PEAK["mfma_bf16"]
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(tf / peak, 4), "traffic": None, "avg_ms": round(top["avg_ms"], 4), "calls_per_step": top["calls"] / args.steps,
+                               "mfma_dtype": "f32" if mfma_f32 else "bf16"}
+            out["kernel_ms_per_step"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in table[:10]}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(min(cores, 16))  # the GPU box gives one GPU's share of host cores (16)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

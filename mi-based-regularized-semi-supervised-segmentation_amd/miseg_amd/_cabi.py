@@ -65,6 +65,9 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise MisegError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
                              f"`make -C {os.path.join(PKG_ROOT, 'csrc')}` -- there is no CPU fallback")
+        # torch first: it bundles its own libamdhip64.so.7; loading ours first would bind /opt/rocm's copy of the
+        # same SONAME into the process and the two runtimes then disagree about the device.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in PROTOTYPES.items():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
