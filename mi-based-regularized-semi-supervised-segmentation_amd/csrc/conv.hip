@@ -266,6 +266,109 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_wgrad_kernel(ConvSrc src, int 
     for (int e = tid; e < 32 * 288; e += kCT) outp[e] = Ds[e];
 }
 
+// bf16 variant: both operands need 8 consecutive PIXELS per lane for a fixed channel, while NHWC keeps channels
+// contiguous -> the LDS tiles stay in their natural [pixel][16 channels] shape (32-byte rows: the 8 rows a 32-lane
+// half touches tile the 64 banks exactly) and fragments come out of ds_read_b64_tr_b16 (hardware 4x16 transpose):
+// lane 4q+p of a 16-lane group supplies (pixel 8g+q, channels 4p..4p+3) and receives its channel's 4 pixels.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+#define LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
+
+__device__ __forceinline__ bf16x8_t tr_frag(const short* blk_px0, int q, int p) {
+    // blk_px0: first pixel (of this lane group's 8) of a [pixel][16] sub-tile
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(blk_px0 + q * 16 + 4 * p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(blk_px0 + (4 + q) * 16 + 4 * p));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, f);
+}
+
+__global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ gout,
+                                                                   int Cout, int nsplit, float* __restrict__ partials) {
+    constexpr int IW = WG_TW + 2, NPX = WG_TH * WG_TW, NIPX = (WG_TH + 2) * IW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
+    short* Gs = reinterpret_cast<short*>(wsm_raw);            // [2][NPX][16]
+    short* Is = Gs + 2 * NPX * 16;                            // [2][NIPX][16]
+    const int Cin = src.C0 + src.C1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int g8 = 8 * kq, q = (lane >> 2) & 3, p4 = lane & 3;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const int tilesC = (W + WG_TW - 1) / WG_TW, tilesR = (H + WG_TH - 1) / WG_TH;
+    const int ntiles = N * tilesR * tilesC;
+    f32x4 acc[2][18];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 18; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+        __syncthreads();
+        for (int idx = tid; idx < NPX * 4; idx += kCT) {
+            const int v = idx & 3, px = idx >> 2, ix = px % WG_TW, iy = px / WG_TW;
+            const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
+            uint4 val = zero4;
+            if (h < H && w < W && c < Cout) val = *reinterpret_cast<const uint4*>(gout + (((size_t)n * H + h) * W + w) * Cout + c);
+            *reinterpret_cast<uint4*>(Gs + ((v >> 1) * NPX + px) * 16 + (v & 1) * 8) = val;
+        }
+        for (int idx = tid; idx < NIPX * 4; idx += kCT) {
+            const int v = idx & 3, px = idx >> 2, ix = px % IW, iy = px / IW;
+            const int h = h0 - 1 + iy, w = w0 - 1 + ix, cc = ci0 + v * 8;
+            uint4 val = zero4;
+            if (h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
+                const bf16* sp;
+                if (cc < src.C0) {
+                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                    sp = reinterpret_cast<const bf16*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + cc;
+                } else {
+                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                    sp = reinterpret_cast<const bf16*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + cc - src.C0;
+                }
+                val = *reinterpret_cast<const uint4*>(sp);
+            }
+            *reinterpret_cast<uint4*>(Is + ((v >> 1) * NIPX + px) * 16 + (v & 1) * 8) = val;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wv * 2 + rr;
+            const bf16x8_t a0 = tr_frag(Gs + (0 * NPX + row * WG_TW + g8) * 16, q, p4);
+            const bf16x8_t a1 = tr_frag(Gs + (1 * NPX + row * WG_TW + g8) * 16, q, p4);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int ipx = (row + ky) * IW + g8 + kx;
+                const bf16x8_t b0 = tr_frag(Is + (0 * NIPX + ipx) * 16, q, p4);
+                const bf16x8_t b1 = tr_frag(Is + (1 * NIPX + ipx) * 16, q, p4);
+                acc[0][tap * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[0][tap * 2 + 0], 0, 0, 0);
+                acc[0][tap * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[0][tap * 2 + 1], 0, 0, 0);
+                acc[1][tap * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[1][tap * 2 + 0], 0, 0, 0);
+                acc[1][tap * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[1][tap * 2 + 1], 0, 0, 0);
+            }
+        }
+    }
+    // reduce the 4 waves in LDS (fixed order), write partial [split][co 32][tap 9][ci 32]
+    float* Ds = reinterpret_cast<float*>(wsm_raw);  // 32 x 288 floats = 36.9 KB (fits: G+I tiles are 38.1 KB)
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 18; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = a * 16 + kq * 4 + r, col = (b / 2) * 32 + (b % 2) * 16 + l15;
+                        if (w == 0) Ds[co * 288 + col] = acc[a][b][r];
+                        else Ds[co * 288 + col] += acc[a][b][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* outp = partials + (((size_t)split * gridDim.z + blockIdx.z) * gridDim.y + blockIdx.y) * (32 * 288);
+    for (int e = tid; e < 32 * 288; e += kCT) outp[e] = Ds[e];
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int Cout, int Cin, int nco, int nci, float* __restrict__ gw) {
     const int total = Cout * Cin * 9;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -430,8 +533,10 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
         hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<float>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws);
     } else if (dt == MISEG_BF16) {
-        hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<bf16>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
+        MISEG_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "conv3x3_wgrad: bf16 needs channel counts that are multiples of 8");
+        const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2, (size_t)32 * 288 * 4);
+        hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbb);
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, grid, dim3(kCT), lbb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
     } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
     MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     const int total = (int)(Cout * Cin * 9);

@@ -65,16 +65,18 @@ def test_epocher_matches_reference_run(golden, mode):
     ref = dict(zip([str(k) for k in g[f"{mode}/meter_keys"]], g[f"{mode}/meter_values"]))
     assert set(got) == set(ref), set(got) ^ set(ref)                      # identical meter names
     np.testing.assert_allclose(got["lr/mean"], ref["lr/mean"], rtol=1e-12)
-    # mean over 2 iterations: the 2nd sees weights after one Adam step, where sign-noise gradients move a few weights
-    # by +-lr differently than in the reference run -> 1e-4-level loss differences
-    np.testing.assert_allclose(got["sup_loss/mean"], ref["sup_loss/mean"], rtol=3e-4)
+    # The golden meters are means over 2 iterations.  Iteration 2 runs on weights after one Adam step, and Adam moves
+    # every weight by ~lr whatever its gradient size: parameters whose gradient is rounding noise step +-lr by the
+    # sign of that noise, so iteration-2 losses of two correct implementations differ at the 1e-3..1e-1 level
+    # (UDA most).  Hence: loose bounds on the 2-iteration means here, tight bounds on iteration 1 below.
+    np.testing.assert_allclose(got["sup_loss/mean"], ref["sup_loss/mean"], rtol=3e-3)
     for k in ("sup_dice/DSC1", "sup_dice/DSC2", "sup_dice/DSC3", "sup_dice/DSC_mean"):
-        np.testing.assert_allclose(got[k], ref[k], rtol=2e-3)            # integer counts; an argmax tie can move a pixel
-    np.testing.assert_allclose(got["reg_loss/mean"], ref["reg_loss/mean"], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(got[k], ref[k], rtol=2e-2)
+    np.testing.assert_allclose(got["reg_loss/mean"], ref["reg_loss/mean"], rtol=0.2, atol=1e-7)
     if mode == "udaiic":
-        np.testing.assert_allclose(got["uda/mean"], ref["uda/mean"], rtol=2e-3)
+        np.testing.assert_allclose(got["uda/mean"], ref["uda/mean"], rtol=0.2)
         for k in ("mi/mean", "individual_mis/Conv5", "individual_mis/Up_conv3", "individual_mis/Up_conv2"):
-            np.testing.assert_allclose(got[k], ref[k], rtol=2e-3, atol=2e-6)  # MI of an untrained head: O(1e-3..1e-6), see test_gpu_mi
+            np.testing.assert_allclose(got[k], ref[k], rtol=0.2, atol=5e-6)
         assert got["iic_weight/mean"] == ref["iic_weight/mean"] and got["uda_weight/mean"] == ref["uda_weight/mean"]
     # weights after two Adam steps: every entry moved by at most ~lr per step; sign-noise gradients bound the deviation
     for k, v in model.state_dict().items():
@@ -98,3 +100,42 @@ def test_udaiic_step_bf16_runs_and_tracks_fp32(golden):
     np.testing.assert_allclose(res["sup_loss"]["mean"], ref["sup_loss/mean"], rtol=2e-2)
     np.testing.assert_allclose(res["uda"]["mean"], ref["uda/mean"], rtol=0.25)
     assert abs(res["mi"]["mean"] - ref["mi/mean"]) < 0.5 * abs(ref["mi/mean"]) + 1e-4
+
+
+@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+def test_first_iteration_is_tight(golden, mode):
+    """Iteration 1 (identical weights on both sides): every meter of the HIP epocher vs the oracle step, which is
+    itself pinned to the reference run by tests/test_oracle_golden.py::test_full_step."""
+    from oracle import step as OS
+    from oracle import losses as OL
+    from semi_seg.epocher import TrainEpocher, UDAIICEpocher
+    g = golden("step")
+    model, pw, lw, opt, lab, unl, kl = build(mode)
+    fi = [float(v) for v in g[f"{mode}/feature_importance"]]
+    random.seed(1234)
+    if mode == "udaiic":
+        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0, device=DEV,
+                           feature_position=FEATURES, feature_importance=fi, cons_weight=STEP["cons_weight"], iic_weight=STEP["iic_weight"])
+    else:
+        ep = TrainEpocher(model, opt, lab, unl, kl, 0, 1, 0, DEV, feature_position=FEATURES, feature_importance=fi)
+    res = ep.run()
+    H, LB, UB = STEP["H"], STEP["LB"], STEP["UB"]
+    heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=10), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=11),
+             "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=12)}
+    state = OS.StepState(OU.init_state(1, 4, seed=9), heads if mode == "udaiic" else {}, lr=STEP["lr"], weight_decay=STEP["wd"])
+    limg = T(synth.uniform(f"step/{mode}/lab0", (LB, 1, H, H)))
+    ltgt = T(synth.integers(f"step/{mode}/tgt0", (LB, 1, H, H), 4))
+    uimg = T(synth.uniform(f"step/{mode}/unl0", (UB, 1, H, H)))
+    sc, _ = OS.train_step(state, limg, ltgt, uimg, int(g[f"{mode}/seeds"][0]), mode=mode, feature_importance=fi,
+                          cons_weight=STEP["cons_weight"], iic_weight=STEP["iic_weight"], do_update=False)
+    np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5)            # north-star 1e-5 class
+    np.testing.assert_allclose(res["reg_loss"]["mean"], sc["reg_loss"], rtol=2e-4, atol=1e-7)
+    dice = OL.DiceMeter(4, report_axis=[1, 2, 3])
+    dice.add(sc["pred"], ltgt.squeeze(1), group_name=[f"patient{j:03d}_00" for j in range(LB)])
+    for k, v in dice.summary().items():
+        np.testing.assert_allclose(res["sup_dice"][k], v, rtol=2e-3)   # integer counts; one argmax tie may move a pixel
+    if mode == "udaiic":
+        np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4)
+        np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
+        for f in FEATURES:
+            np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
