@@ -71,7 +71,7 @@ def test_epocher_matches_reference_run(golden, mode):
     # (UDA most).  Hence: loose bounds on the 2-iteration means here, tight bounds on iteration 1 below.
     np.testing.assert_allclose(got["sup_loss/mean"], ref["sup_loss/mean"], rtol=3e-3)
     for k in ("sup_dice/DSC1", "sup_dice/DSC2", "sup_dice/DSC3", "sup_dice/DSC_mean"):
-        np.testing.assert_allclose(got[k], ref[k], rtol=2e-2)
+        np.testing.assert_allclose(got[k], ref[k], rtol=2e-2, atol=5e-3)   # rare classes: a few pixels move a 1e-2 Dice
     np.testing.assert_allclose(got["reg_loss/mean"], ref["reg_loss/mean"], rtol=0.2, atol=1e-7)
     if mode == "udaiic":
         np.testing.assert_allclose(got["uda/mean"], ref["uda/mean"], rtol=0.2)
