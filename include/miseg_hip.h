@@ -60,7 +60,9 @@ const char* miseg_last_error(void);
  *             (:139-146).  Writes loss[P] and grad_raw[P][T][T][K][K] = d loss[p] / d raw[p].
  * bwd       : gx, gy [N,K,H,W] += sum_p scale[p] * (d loss[p]/d x, y) through the joint and mask.
  *             scale = fp32[P] DEVICE array (upstream grad / P, the average_iter at :186).
- *             gx, gy must be zero-initialised by the caller when accumulate == 0 is not used.
+ *             The windows of ONE call must be pairwise disjoint (the host colours overlapping patches into
+ *             groups).  accumulate = 0: plain stores -- legal only if the call's windows cover every pixel
+ *             of the map (e.g. the single whole-map window); accumulate = 1: gx, gy += (caller zero-fills).
  * ------------------------------------------------------------------------------------------ */
 int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P);
 int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, const float* mask, int64_t N,
@@ -70,7 +72,7 @@ int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t 
                              float* loss, float* grad_raw);
 int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
                         int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
-                        const float* grad_raw, const float* scale, float* gx, float* gy);
+                        const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate);
 
 /* ------------------------------------------------------------------------------------------
  * Global IIC mutual information, S sub-heads in one launch

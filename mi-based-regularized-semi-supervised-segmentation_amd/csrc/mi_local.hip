@@ -427,6 +427,205 @@ __global__ __launch_bounds__(kThreads, 1) void local_bwd_kernel(const float* __r
     }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Backward, transposed-GEMM form (the fast path).  For one output row h of direction "gx":
+//   dA[(b,i), w] = sum_{(a,j)} G[a,b,i,j] * Y[j][h-(a-p)][w]          GEMM: M=(b,i)=T*K, Kred=(a,j)=T*K, N=pixels
+//   gx[i][h][w'] = sum_b dA[(b,i), w'-(b-p)]                           "col2im": 7 shifted adds
+// (gy: swap roles, mirror the shifts).  M is padded 140->144 only (97 %), N tiles of 16 columns carry a 2p halo
+// (58 of 64 useful for p=3), Kred is exact -- versus 20->32 rows (62.5 %) in the direct form above.
+// The shifted adds go through ds_add_f32 into a per-wave [K][64] LDS row buffer: lanes of one accumulator
+// register never collide (a 16-row tile holds each channel i at most once) and program order fixes the
+// summation order, so the result stays deterministic.
+// -------------------------------------------------------------------------------------------
+struct Bwd2Geom {
+    int N, K, Kc, H, W, pad, T, P;
+    int Mdim, Kred, ksteps;     // T*K, T*Kc, Kred/4
+    int WB, RS, planeS, gstride;  // useful output columns per tile (64-2p), src rows (4+2p), plane stride, G row stride
+    int G;
+    int plain_rmw;   // col2im may use plain LDS read-modify-write (no two lanes of one instruction share an address)
+    int accumulate;  // 0: plain stores (every output pixel is covered exactly once by this call), 1: +=
+    int ablate;  // profiling only (MISEG_ABLATE): 1 no src loads, 2 no MFMA loop, 4 no col2im, 8 no output write
+};
+
+template <int MT>
+__global__ __launch_bounds__(kThreads, 1) void local_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ mask, Bwd2Geom g,
+                                                                   const int32_t* __restrict__ win,
+                                                                   const float* __restrict__ grad_raw,
+                                                                   const float* __restrict__ scale, float* __restrict__ gx,
+                                                                   float* __restrict__ gy) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = 4, WT = 64;                       // 4 pixel tiles = 64 columns (incl. 2p halo)
+    constexpr int OWS = 68;                              // Ow row stride: 4*OWS = 16 (mod 32) -> the two kq groups of a
+                                                         // 32-lane half land on disjoint bank ranges (conflict-free ds_add)
+    float* Gs = lds;                                     // [MT*16][gstride]   A operand: Gm[(b,o)][(a,c)]
+    float* Ss = Gs + (size_t)MT * 16 * g.gstride;        // [Kc][RS][WT] src tile (cols col0-p .. col0-p+63)
+    float* Os = Ss + (size_t)g.Kc * g.planeS;            // [4 waves][K][OWS] output row buffers
+    int* Mtab = reinterpret_cast<int*>(Os + (size_t)4 * g.K * OWS);  // [MT*16] row m -> (shift << 16) | o, -1 for padding
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int TT = g.T * g.T, KK = g.K * g.K;
+    const size_t plane = (size_t)g.H * g.W;
+    float* Ow = Os + (size_t)wv * g.K * OWS;
+
+    int64_t total = 0;
+    for (int p = 0; p < g.P; ++p) {
+        int tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4, tc = (win[p * 4 + 3] - win[p * 4 + 2] + g.WB - 1) / g.WB;
+        total += (int64_t)g.N * tr * tc;
+    }
+    int arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = min(mt * 16 + l15, g.Mdim - 1) * g.gstride + kq;
+
+    // ---- work decode + register-staged prefetch of the src tile (loads of item k+1 fly during the MFMAs of item k)
+    constexpr int PF = 10;   // rows per (wave, channel) batch: RS = 4 + 2*pad <= 10 on this path (pad <= 3, checked on host)
+    constexpr int CHW = 5;   // channels per wave: Kc <= 20
+    struct Item { int dir, p, n, row0, col0, h0, h1, w0, w1; };
+    auto decode = [&](int64_t it, Item& q) {
+        q.dir = it >= total;
+        int64_t rem = it - (q.dir ? total : 0);
+        int p = 0, tr = 0, tc = 0;
+        for (; p < g.P; ++p) {
+            tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4;
+            tc = (win[p * 4 + 3] - win[p * 4 + 2] + g.WB - 1) / g.WB;
+            int64_t cnt = (int64_t)g.N * tr * tc;
+            if (rem < cnt) break;
+            rem -= cnt;
+        }
+        q.p = p;
+        q.h0 = win[p * 4 + 0]; q.h1 = win[p * 4 + 1]; q.w0 = win[p * 4 + 2]; q.w1 = win[p * 4 + 3];
+        const int ct = rem % tc, rt = (rem / tc) % tr;
+        q.n = rem / ((int64_t)tc * tr);
+        q.row0 = q.h0 + rt * 4; q.col0 = q.w0 + ct * g.WB;
+    };
+    float pf[CHW][PF];
+    auto prefetch = [&](const Item& q) {
+        const float* src = q.dir ? x : y;
+        const int col = q.col0 - g.pad + lane;
+        const bool colok = col >= q.w0 && col < q.w1 && !(g.ablate & 1);
+#pragma unroll
+        for (int cw = 0; cw < CHW; ++cw) {
+            const int ch = wv + 4 * cw;
+#pragma unroll
+            for (int r = 0; r < PF; ++r) {
+                const int row = q.row0 - g.pad + r;
+                float v = 0.f;
+                if (r < g.RS && colok && ch < g.K && row >= q.h0 && row < q.h1) {
+                    const size_t o = (size_t)row * g.W + col;
+                    v = src[((size_t)q.n * g.K + ch) * plane + o];
+                    if (mask) v *= mask[(size_t)q.n * plane + o];
+                }
+                pf[cw][r] = v;
+            }
+        }
+    };
+    auto commit = [&]() {  // registers -> LDS tile
+#pragma unroll
+        for (int cw = 0; cw < CHW; ++cw) {
+            const int ch = wv + 4 * cw;
+            if (ch < g.Kc) {
+#pragma unroll
+                for (int r = 0; r < PF; ++r)
+                    if (r < g.RS) Ss[ch * g.planeS + r * WT + lane] = pf[cw][r];
+            }
+        }
+    };
+
+    int curKey = -1;
+    Item cur, nxt;
+    if ((int64_t)blockIdx.x < 2 * total) { decode(blockIdx.x, cur); prefetch(cur); }
+    for (int64_t it = blockIdx.x; it < 2 * total; it += g.G) {
+        const int dir = cur.dir, p = cur.p, n = cur.n, row0 = cur.row0, col0 = cur.col0, h1 = cur.h1, w1 = cur.w1;
+        float* out = dir ? gy : gx;
+        const int sgn = dir ? 1 : -1;
+        const float* G = grad_raw + (size_t)p * TT * KK;
+
+        __syncthreads();   // previous item's tile and G fully consumed
+        if (curKey != p * 2 + dir) {
+            curKey = p * 2 + dir;
+            // Gs[m=(b,o)][kred=(a,c)] = dir ? G[a,b,c,o] : G[a,b,o,c]   (zero for padded c); one row m per wave-iteration
+            for (int m = wv; m < g.Mdim; m += 4) {
+                const int b = m / g.K, o = m % g.K;
+                for (int kr = lane; kr < g.Kred; kr += 64) {
+                    const int a = kr / g.Kc, c = kr % g.Kc;
+                    float v = 0.f;
+                    if (c < g.K) v = dir ? G[((size_t)(a * g.T + b)) * KK + c * g.K + o] : G[((size_t)(a * g.T + b)) * KK + o * g.K + c];
+                    Gs[m * g.gstride + kr] = v;
+                }
+            }
+            for (int m = tid; m < MT * 16; m += kThreads)
+                Mtab[m] = m < g.Mdim ? ((((-sgn * (m / g.K - g.pad)) + 64) << 16) | (m % g.K)) : -1;
+        }
+        commit();
+        for (int o = 0; o < g.K; ++o) Ow[o * OWS + lane] = 0.f;
+        __syncthreads();
+        const bool more = it + g.G < 2 * total;
+        if (more) { decode(it + g.G, nxt); prefetch(nxt); }   // global loads in flight across the MFMA phase
+
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // reduction index kred = a*Kc + c; 4 consecutive c per MFMA k-step
+        const int cper = g.Kc / 4;
+        for (int a = 0; a < ((g.ablate & 2) ? 0 : g.T); ++a) {
+            // src row for output row (row0+wv): h + sgn*(a-pad)  -> tile row wv + pad + sgn*(a-pad)
+            const float* sp = Ss + (wv + g.pad + sgn * (a - g.pad)) * WT + l15 + kq * g.planeS;
+            const int kbase = a * g.Kc;
+            for (int cs = 0; cs < cper; ++cs) {
+                float av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = Gs[arow[mt] + kbase + 4 * cs];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = sp[(4 * cs) * g.planeS + nt * 16];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        // col2im: D[m=(b,o)][tile col w] -> Ow[o][w + shift(b)]:  gx: w' = w + (b-p); gy: w' = w - (b-p)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = Mtab[mt * 16 + kq * 4 + r];
+                if (e >= 0 && !(g.ablate & 4)) {
+                    const int o = e & 0xffff, shift = (e >> 16) - 64;
+                    float* orow = Ow + o * OWS + shift + l15;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int wc = nt * 16 + l15 + shift;
+                        if (wc >= 0 && wc < WT) {
+                            // rows kq*4+r of one instruction hold distinct channels unless K divides 4, 8 or 12
+                            if (g.plain_rmw) orow[nt * 16] += acc[mt][nt][r];
+                            else atomicAdd(orow + nt * 16, acc[mt][nt][r]);
+                        }
+                    }
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // write the valid columns [pad, pad+WB) of this wave's row: one coalesced row segment per channel
+        const int row = row0 + wv;
+        const int col = col0 + lane;
+        if (row < h1 && lane < g.WB && col < w1 && !(g.ablate & 8)) {
+            const float sc = scale[p];
+            const size_t po = (size_t)row * g.W + col;
+            const float mk = sc * (mask ? mask[(size_t)n * plane + po] : 1.f);
+            float* op = out + (size_t)n * g.K * plane + po;
+            if (g.accumulate) {
+                for (int o = 0; o < g.K; ++o) op[(size_t)o * plane] += mk * Ow[o * OWS + g.pad + lane];
+            } else {
+                for (int o = 0; o < g.K; ++o) op[(size_t)o * plane] = mk * Ow[o * OWS + g.pad + lane];
+            }
+        }
+        cur = nxt;
+    }
+}
+
 }  // namespace miseg
 
 using namespace miseg;
@@ -482,9 +681,38 @@ extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t 
 
 extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
                                    int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw,
-                                   const float* scale, float* gx, float* gy) {
+                                   const float* scale, float* gx, float* gy, int accumulate) {
     MISEG_REQUIRE(x && y && win && grad_raw && scale && gx && gy, "iic_local_bwd: null pointer");
     MISEG_REQUIRE(N > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_bwd: bad shape (K<=32)");
+    hipStream_t st = as_stream(stream);
+    {   // fast path: transposed GEMM + LDS col2im (needs T*K <= 144 rows and the G matrix + tiles in LDS)
+        Bwd2Geom b2;
+        b2.N = (int)N; b2.K = (int)K; b2.Kc = ((int)K + 3) & ~3; b2.H = (int)H; b2.W = (int)W; b2.pad = (int)pad; b2.T = 2 * (int)pad + 1;
+        b2.P = (int)P; b2.Mdim = b2.T * b2.K; b2.Kred = b2.T * b2.Kc; b2.ksteps = b2.Kred / 4;
+        b2.WB = 64 - 2 * b2.pad; b2.RS = 4 + 2 * b2.pad; b2.planeS = (b2.RS * 64) | 1; b2.gstride = b2.Kred | 1; b2.G = 256;
+        { const char* ab = getenv("MISEG_ABLATE"); b2.ablate = ab ? atoi(ab) : 0; }
+        const int mt = (b2.Mdim + 15) / 16;
+        const int mtc = mt <= 4 ? 4 : 9;
+        const size_t lds2 = ((size_t)mtc * 16 * b2.gstride + (size_t)b2.Kc * b2.planeS + (size_t)4 * b2.K * 68 + (size_t)mtc * 16) * 4;
+        b2.accumulate = accumulate;
+        b2.plain_rmw = (4 % b2.K != 0) && (8 % b2.K != 0) && (12 % b2.K != 0);
+        if (getenv("MISEG_COL2IM_ATOMIC")) b2.plain_rmw = 0;
+        if (mt <= 9 && b2.WB >= 16 && b2.RS <= 10 && b2.Kc <= 20 && lds2 <= (size_t)kLdsBudget) {
+            if (mtc == 4) {
+                hipFuncSetAttribute((const void*)local_bwd2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL((local_bwd2_kernel<4>), dim3(b2.G), dim3(kThreads), lds2, st, x, y, mask, b2, win, grad_raw, scale, gx, gy);
+            } else {
+                hipFuncSetAttribute((const void*)local_bwd2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL((local_bwd2_kernel<9>), dim3(b2.G), dim3(kThreads), lds2, st, x, y, mask, b2, win, grad_raw, scale, gx, gy);
+            }
+            MISEG_LAUNCH_CHECK("local_bwd2_kernel");
+            return MISEG_OK;
+        }
+    }
+    if (!accumulate) {  // the direct-form fallback below always accumulates
+        hipMemsetAsync(gx, 0, (size_t)N * K * H * W * sizeof(float), st);
+        hipMemsetAsync(gy, 0, (size_t)N * K * H * W * sizeof(float), st);
+    }
     BwdGeom g;
     g.N = (int)N; g.K = (int)K; g.Kc = ((int)K + 3) & ~3; g.H = (int)H; g.W = (int)W; g.pad = (int)pad; g.T = 2 * (int)pad + 1;
     g.P = (int)P; g.RS = 4 + 2 * g.pad;
@@ -504,7 +732,6 @@ extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y,
     }
     MISEG_REQUIRE(ntp, "iic_local_bwd: K=%ld pad=%ld does not fit LDS", (long)K, (long)pad);
     g.G = 256;
-    hipStream_t st = as_stream(stream);
 #define MISEG_BWD_LAUNCH(NTP)                                                                                         \
     hipFuncSetAttribute((const void*)local_bwd_kernel<NTP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);   \
     hipLaunchKernelGGL((local_bwd_kernel<NTP>), dim3(g.G), dim3(kThreads), ldsb, st, x, y, mask, g, win, grad_raw, scale, gx, gy)
