@@ -194,6 +194,140 @@ __global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restri
     if (tid < R) out[R * C + tid] = gbacc;
 }
 
+// Fused backward of the local head (replaces the dz + weight-gradient kernel pair and their 2 x 840 MB dz round
+// trip at the cfg2 shape).  One block = one 64-pixel chunk at a time (persistent, strided):
+//   phase 1 (VALU, streaming): dz[(s,k)][px] = p*(g - <g,p>)/T from prob/gprob (coalesced along pixels) -> LDS
+//   phase 2 (fp32 MFMA):       gfeat[px][c] = sum_(s,k) dz[(s,k)][px] * W[(s,k)][c]     (M=px, N=c, Kred=S*K)
+//   phase 3 (fp32 MFMA):       gw[(s,k)][c] += sum_px dz[(s,k)][px] * f[px][c]          (M=(s,k), N=c, Kred=px)
+// gw / gb accumulate in registers across the block's chunks; one deterministic partial per block at the end.
+template <typename T, int CTM>
+__global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
+                                                                   const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
+                                                                   int M, const float* __restrict__ w, int S, int K, float invT,
+                                                                   const float* __restrict__ prob, const float* __restrict__ gprob,
+                                                                   T* __restrict__ gfeat, float* __restrict__ partials, int nblk) {
+    extern __shared__ float sm[];
+    const int R = S * K, RT = (R + 15) / 16, RP = RT * 16, CT = (C + 15) / 16, HW = H * W;
+    constexpr int DZS = 65;
+    const int FS = C + 1, WS = C + 1;
+    float* dzs = sm;                          // [RP][DZS]   dz, rows >= R zero
+    float* fs = dzs + (size_t)RP * DZS;       // [64][FS]    feature chunk (fp32)
+    float* wsm = fs + (size_t)64 * FS;        // [RP][WS]    head weights, rows >= R zero
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    for (int idx = tid; idx < RP * C; idx += 256) {
+        const int c = idx % C, r = idx / C;
+        wsm[r * WS + c] = r < R ? w[(size_t)r * C + c] : 0.f;
+    }
+    for (int idx = tid; idx < (RP - R) * 64; idx += 256) dzs[(R + idx / 64) * DZS + (idx & 63)] = 0.f;
+    f32x4 accw[4][CTM];   // gw: row tiles rt = wv + 4a, column tiles c
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < CTM; ++c) accw[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gbacc = 0.f;
+    const int chunksPerM = (HW + 63) / 64;
+    const int64_t nchunks = (int64_t)M * chunksPerM;
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += nblk) {
+        const int m = ch / chunksPerM, p0 = (ch % chunksPerM) * 64;
+        const int f = flips ? flips[m] : 0;
+        const int px = lane, pix = p0 + px;
+        const bool live = pix < HW;
+        __syncthreads();
+        // ---- phase 1: dz for sub-heads s = wv, wv+4, ...
+        for (int s = wv; s < S; s += 4) {
+            const size_t base = (((size_t)s * M + m) * K) * HW + pix;
+            float dot = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float pv = live ? prob[base + (size_t)k * HW] : 0.f, gv = live ? gprob[base + (size_t)k * HW] : 0.f;
+                dzs[(s * K + k) * DZS + px] = pv;
+                dot += pv * gv;
+            }
+            for (int k = 0; k < K; ++k) {
+                const float pv = dzs[(s * K + k) * DZS + px], gv = live ? gprob[base + (size_t)k * HW] : 0.f;
+                dzs[(s * K + k) * DZS + px] = pv * (gv - dot) * invT;
+            }
+        }
+        // feature chunk (flip-aware gather), one pixel row of C channels per thread-iteration
+        for (int idx = tid; idx < 64 * C; idx += 256) {
+            const int c = idx % C, q = idx / C;
+            float v = 0.f;
+            if (p0 + q < HW) {
+                const int pq = p0 + q, h = pq / W, wq = pq % W;
+                v = to_f32(feat[((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c]);
+            }
+            fs[q * FS + c] = v;
+        }
+        __syncthreads();
+        if (tid < R) {
+            float a = 0.f;
+            for (int q = 0; q < 64; ++q) a += dzs[tid * DZS + q];
+            gbacc += a;
+        }
+        // ---- phase 2: gfeat tile [64 px][C]: wave wv owns pixel tile wv (16 px)
+        if (gfeat) {
+            f32x4 accf[CTM];
+#pragma unroll
+            for (int c = 0; c < CTM; ++c) accf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < RP; ks += 4) {
+                const float av = dzs[(ks + kq) * DZS + wv * 16 + l15];
+#pragma unroll
+                for (int c = 0; c < CTM; ++c)
+                    if (c < CT) {
+                        const float bv = wsm[(ks + kq) * WS + min(c * 16 + l15, C - 1)];
+                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accf[c], 0, 0, 0);
+                    }
+            }
+            // D[row = pixel kq*4+r][col = channel l15]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pq = p0 + wv * 16 + kq * 4 + r;
+                if (pq < HW) {
+                    const int h = pq / W, wq = pq % W;
+                    T* gp = gfeat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+#pragma unroll
+                    for (int c = 0; c < CTM; ++c) {
+                        const int cc = c * 16 + l15;
+                        if (c < CT && cc < C) gp[cc] = from_f32<T>(to_f32(gp[cc]) + accf[c][r]);
+                    }
+                }
+            }
+        }
+        // ---- phase 3: gw += dz * f
+        for (int ks = 0; ks < 64; ks += 4) {
+            float bfr[CTM];
+#pragma unroll
+            for (int c = 0; c < CTM; ++c) bfr[c] = (c < CT) ? fs[(ks + kq) * FS + min(c * 16 + l15, C - 1)] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int rt = wv + 4 * a;
+                if (rt < RT) {
+                    const float av = dzs[(rt * 16 + l15) * DZS + ks + kq];
+#pragma unroll
+                    for (int c = 0; c < CTM; ++c)
+                        if (c < CT) accw[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfr[c], accw[a][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = partials + (size_t)blockIdx.x * (R * C + R);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int rt = wv + 4 * a;
+        if (rt < RT) {
+#pragma unroll
+            for (int c = 0; c < CTM; ++c)
+                if (c < CT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = rt * 16 + kq * 4 + r, col = c * 16 + l15;
+                        if (row < R && col < C) out[row * C + col] = accw[a][c][r];
+                    }
+                }
+        }
+    }
+    if (tid < R) out[R * C + tid] = gbacc;
+}
+
 __global__ void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ outA, int lenA,
                                     float* __restrict__ outB) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
@@ -228,10 +362,10 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
     return MISEG_OK;
 }
 
-static int head_w_blocks(int64_t M, int64_t HW) { return (int)std::min<int64_t>(M * cdiv(HW, 64), 512); }
+static int head_w_blocks(int64_t M, int64_t HW) { return (int)std::min<int64_t>(M * cdiv(HW, 64), 768); }
 
 extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K) {
-    return (S * M * K * H * W + (int64_t)head_w_blocks(M, H * W) * (S * K * C + S * K)) * 4;
+    return ((int64_t)head_w_blocks(M, H * W) * (S * K * C + S * K)) * 4;
 }
 
 extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
@@ -242,29 +376,23 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 128 && K > 0 && K <= 64 && S * K <= 256 && M > 0, "head_local_bwd: need C%%4==0, C<=128, S*K<=256");
     MISEG_REQUIRE(ws_bytes >= miseg_head_local_bwd_ws_bytes(M, H, W, C, S, K), "head_local_bwd: workspace too small");
     hipStream_t st = as_stream(stream);
-    float* dz = (float*)ws;
-    float* partials = dz + (size_t)S * M * K * H * W;
-    dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
-    size_t ldsb = (size_t)K * kHT * 4;
-    const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16;
-    size_t ldsw = ((size_t)RT * 16 * 65 + (size_t)64 * (C + 1)) * 4;
-    if (dt == MISEG_F32) {
-        hipLaunchKernelGGL(head_local_bwd_dz_kernel<float>, grid, dim3(kHT), ldsb, st, (int)H, (int)W, (int)C, src, flips, (int)M, w,
-                           (int)S, (int)K, 1.0f / T, prob, gprob, dz, (float*)gfeat);
-        MISEG_LAUNCH_CHECK("head_local_bwd_dz_kernel");
-        hipFuncSetAttribute((const void*)head_local_bwd_w_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-        hipLaunchKernelGGL(head_local_bwd_w_kernel<float>, dim3(nblk), dim3(256), ldsw, st, (const float*)feat, (int)H, (int)W, (int)C,
-                           src, flips, (int)M, (int)S, (int)K, dz, partials, nblk);
-    } else if (dt == MISEG_BF16) {
-        hipLaunchKernelGGL(head_local_bwd_dz_kernel<bf16>, grid, dim3(kHT), ldsb, st, (int)H, (int)W, (int)C, src, flips, (int)M, w,
-                           (int)S, (int)K, 1.0f / T, prob, gprob, dz, (bf16*)gfeat);
-        MISEG_LAUNCH_CHECK("head_local_bwd_dz_kernel");
-        hipFuncSetAttribute((const void*)head_local_bwd_w_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-        hipLaunchKernelGGL(head_local_bwd_w_kernel<bf16>, dim3(nblk), dim3(256), ldsw, st, (const bf16*)feat, (int)H, (int)W, (int)C,
-                           src, flips, (int)M, (int)S, (int)K, dz, partials, nblk);
-    } else
-        return fail(MISEG_E_INVALID, "head_local_bwd: bad dtype %d", dt);
-    MISEG_LAUNCH_CHECK("head_local_bwd_w_kernel");
+    float* partials = (float*)ws;
+    const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16, RP = RT * 16;
+    const size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1)) * 4;
+    MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
+#define HLB(TT, CTM)                                                                                                              \
+    {                                                                                                                             \
+        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
+                           src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);                \
+    }
+#define HLB_C(TT) { if (C <= 16) HLB(TT, 1) else if (C <= 32) HLB(TT, 2) else if (C <= 64) HLB(TT, 4) else HLB(TT, 8) }
+    if (dt == MISEG_F32) HLB_C(float)
+    else if (dt == MISEG_BF16) HLB_C(bf16)
+    else return fail(MISEG_E_INVALID, "head_local_bwd: bad dtype %d", dt);
+#undef HLB_C
+#undef HLB
+    MISEG_LAUNCH_CHECK("head_local_bwd_fused_kernel");
     const int len = R * (int)C + R;
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, st, partials, nblk, len, gw, R * (int)C, gb);
     MISEG_LAUNCH_CHECK("sum_partials_kernel");
