@@ -89,6 +89,24 @@ __device__ __forceinline__ float block_min(float v, float* red) {
     return red[16];
 }
 
+// Deterministic sum over `nparts` partial vectors: out[e] = sum_q parts[q*stride + map(e)].
+// 64 outputs x 4 split-groups per 256-thread block; each group sums q = g, g+4, ... serially, the 4 group
+// sums are added in fixed order -> bitwise reproducible, 4x the memory-level parallelism of one thread per output.
+template <typename MapFn>
+__device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
+                                                      float* __restrict__ out, MapFn map) {
+    __shared__ float rp_sm[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (e < total) {
+        const size_t off = map(e);
+        for (int q = grp; q < nparts; q += 4) s += parts[(size_t)q * stride + off];
+    }
+    rp_sm[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && e < total) out[e] = ((rp_sm[0][threadIdx.x] + rp_sm[1][threadIdx.x]) + rp_sm[2][threadIdx.x]) + rp_sm[3][threadIdx.x];
+}
+
 // Flip-aware source coordinate: bit0 = flip H, bit1 = flip W.
 __device__ __forceinline__ int flip_h(int h, int H, int f) { return (f & 1) ? (H - 1 - h) : h; }
 __device__ __forceinline__ int flip_w(int w, int W, int f) { return (f & 2) ? (W - 1 - w) : w; }

@@ -369,16 +369,13 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
     for (int e = tid; e < 32 * 288; e += kCT) outp[e] = Ds[e];
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int Cout, int Cin, int nco, int nci, float* __restrict__ gw) {
-    const int total = Cout * Cin * 9;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int Cout, int Cin, int nco,
+                                                           int nci, float* __restrict__ gw) {
+    const size_t stride = (size_t)nco * nci * (32 * 288);
+    reduce_partials_block(partials, nsplit, stride, Cout * Cin * 9, gw, [=](int e) {
         const int tap = e % 9, ci = (e / 9) % Cin, co = e / (9 * Cin);
-        const int bz = co / 32, by = ci / 32;
-        const size_t off = ((size_t)bz * nci + by) * (32 * 288) + (co % 32) * 288 + tap * 32 + (ci % 32);
-        float s = 0.f;
-        for (int q = 0; q < nsplit; ++q) s += partials[(size_t)q * nco * nci * (32 * 288) + off];
-        gw[e] = s;
-    }
+        return ((size_t)(co / 32) * nci + ci / 32) * (32 * 288) + (co % 32) * 288 + tap * 32 + (ci % 32);
+    });
 }
 
 // ------------------------------------------------------------------------------------------ 1x1 logits head
@@ -438,13 +435,8 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
         partials[(size_t)blockIdx.x * (CO * CI + CO) + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
 }
 
-__global__ void sum_parts2_kernel(const float* __restrict__ partials, int nparts, int len, int lenA, float* __restrict__ outA,
-                                  float* __restrict__ outB) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int q = 0; q < nparts; ++q) s += partials[(size_t)q * len + e];
-        if (e < lenA) outA[e] = s; else outB[e - lenA] = s;
-    }
+__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ out) {
+    reduce_partials_block(partials, nparts, (size_t)len, len, out, [](int e) { return (size_t)e; });
 }
 
 static inline int tile_w(int64_t W) { return W >= 32 ? 32 : 16; }
@@ -540,7 +532,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
     } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
     MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     const int total = (int)(Cout * Cin * 9);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
     MISEG_LAUNCH_CHECK("wgrad_reduce_kernel");
     return MISEG_OK;
 }
@@ -567,7 +559,7 @@ extern "C" int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N
 
 static int c1_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv(npix, 256), 1024); }
 extern "C" int64_t miseg_conv1x1_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
-    return (int64_t)c1_blocks(N * H * W) * (Cout * Cin + Cout) * 4;
+    return ((int64_t)c1_blocks(N * H * W) + 1) * (Cout * Cin + Cout) * 4;
 }
 
 extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, int64_t N, int64_t H, int64_t W, int64_t Cin,
@@ -589,7 +581,11 @@ extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const flo
 #undef L
     MISEG_LAUNCH_CHECK("conv1x1_bwd_kernel");
     const int len = (int)(Cout * Cin + Cout);
-    hipLaunchKernelGGL(sum_parts2_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, len, (int)(Cout * Cin), gw, gbias);
+    // gw [Cout*Cin] and gbias [Cout] are reduced into one contiguous scratch vector, then split
+    float* red = (float*)ws + (size_t)nb * len;
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)ws, nb, len, red);
     MISEG_LAUNCH_CHECK("sum_parts2_kernel");
+    hipMemcpyAsync(gw, red, (size_t)Cout * Cin * 4, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(gbias, red + Cout * Cin, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st);
     return MISEG_OK;
 }

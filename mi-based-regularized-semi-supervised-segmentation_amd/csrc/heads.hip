@@ -328,14 +328,8 @@ __global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __re
     if (tid < R) out[R * C + tid] = gbacc;
 }
 
-__global__ void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ outA, int lenA,
-                                    float* __restrict__ outB) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int q = 0; q < nparts; ++q) s += partials[(size_t)q * len + e];
-        if (e < lenA) outA[e] = s;
-        else outB[e - lenA] = s;
-    }
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ out) {
+    reduce_partials_block(partials, nparts, (size_t)len, len, out, [](int e) { return (size_t)e; });
 }
 
 }  // namespace miseg
@@ -365,7 +359,7 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
 static int head_w_blocks(int64_t M, int64_t HW) { return (int)std::min<int64_t>(M * cdiv(HW, 64), 768); }
 
 extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K) {
-    return ((int64_t)head_w_blocks(M, H * W) * (S * K * C + S * K)) * 4;
+    return (((int64_t)head_w_blocks(M, H * W) + 1) * (S * K * C + S * K)) * 4;
 }
 
 extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
@@ -394,7 +388,10 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
 #undef HLB
     MISEG_LAUNCH_CHECK("head_local_bwd_fused_kernel");
     const int len = R * (int)C + R;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(len, 256)), dim3(256), 0, st, partials, nblk, len, gw, R * (int)C, gb);
+    float* red = partials + (size_t)nblk * len;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(len, 64)), dim3(256), 0, st, partials, nblk, len, red);
     MISEG_LAUNCH_CHECK("sum_partials_kernel");
+    hipMemcpyAsync(gw, red, (size_t)R * C * 4, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(gb, red + (size_t)R * C, (size_t)R * 4, hipMemcpyDeviceToDevice, st);
     return MISEG_OK;
 }

@@ -180,20 +180,15 @@ __global__ __launch_bounds__(kJT, 2) void joint_fwd_kernel(const float* __restri
 }
 
 // raw[p][a][b][i][j] = sum_g partial[(p,sm,sn)][g][m = b*K+i][c = a*K+j]   (fixed order => deterministic)
-__global__ void joint_reduce_kernel(const float* __restrict__ partials, JointGeom g, int MTmax, float* __restrict__ raw) {
+__global__ __launch_bounds__(256) void joint_reduce_kernel(const float* __restrict__ partials, JointGeom g, int MTmax, float* __restrict__ raw) {
     const int TT = g.T * g.T, KK = g.K * g.K;
-    const int64_t total = (int64_t)g.P * TT * KK;
     const int Dn = MTmax * 16, Dsz = Dn * Dn;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int j = e % g.K, i = (e / g.K) % g.K, b = (e / KK) % g.T, a = (e / (KK * g.T)) % g.T, p = e / ((int64_t)KK * TT);
-        int m = b * g.K + i, c = a * g.K + j;
-        int sm = m / (g.tps * 16), sn = c / (g.tps * 16);
-        int ml = m - sm * g.tps * 16, cl = c - sn * g.tps * 16;
-        const float* src = partials + ((size_t)((p * g.sb + sm) * g.sb + sn) * g.G) * Dsz + ml * Dn + cl;
-        float s = 0.f;
-        for (int q = 0; q < g.G; ++q) s += src[(size_t)q * Dsz];
-        raw[e] = s;
-    }
+    reduce_partials_block(partials, g.G, (size_t)Dsz, g.P * TT * KK, raw, [=](int e) {
+        const int j = e % g.K, i = (e / g.K) % g.K, b = (e / KK) % g.T, a = (e / (KK * g.T)) % g.T, p = e / (KK * TT);
+        const int m = b * g.K + i, c = a * g.K + j;
+        const int sm = m / (g.tps * 16), sn = c / (g.tps * 16);
+        return ((size_t)((p * g.sb + sm) * g.sb + sn) * g.G) * Dsz + (size_t)(m - sm * g.tps * 16) * Dn + (c - sn * g.tps * 16);
+    });
 }
 
 static bool plan_joint(JointGeom& g, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
@@ -659,8 +654,7 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
     }
     MISEG_LAUNCH_CHECK("joint_fwd_kernel");
     int64_t total = (int64_t)P * g.T * g.T * K * K;
-    int rb = (int)std::min<int64_t>(cdiv(total, 256), 2048);
-    hipLaunchKernelGGL(joint_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, g, cap, raw);
+    hipLaunchKernelGGL(joint_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, (const float*)ws, g, cap, raw);
     MISEG_LAUNCH_CHECK("joint_reduce_kernel");
     return MISEG_OK;
 }

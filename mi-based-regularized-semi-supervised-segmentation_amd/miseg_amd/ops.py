@@ -35,6 +35,26 @@ def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_CONST_CACHE = {}
+
+
+def cached_const(key, build):
+    """Small static device tensors (window lists, gather indices) are built once per (shape, device)."""
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = _CONST_CACHE[key] = build()
+    return t
+
+
+def windows_tensor(windows, device) -> Tensor:
+    key = ("win", str(device), tuple(tuple(int(v) for v in w) for w in windows))
+    return cached_const(key, lambda: torch.tensor([list(w) for w in windows], dtype=torch.int32, device=device).view(len(windows), 4))
+
+
+def arange_i32(start: int, stop: int, device) -> Tensor:
+    return cached_const(("arange", str(device), start, stop), lambda: torch.arange(start, stop, dtype=torch.int32, device=device))
+
+
 def flips_to_tensor(decisions: Sequence[Sequence[bool]], device) -> Tensor:
     """[[flip_h, flip_w], ...] -> int32 bit masks (bit0 = H, bit1 = W)."""
     return torch.tensor([int(bool(fh)) | (int(bool(fw)) << 1) for fh, fw in decisions], dtype=torch.int32, device=device)
@@ -66,7 +86,7 @@ class _LocalMI(torch.autograd.Function):
         n, k, h, w = x.shape
         p = len(windows)
         dev = x.device
-        win = torch.tensor(windows, dtype=torch.int32, device=dev).view(p, 4)
+        win = windows_tensor(windows, dev)
         t = 2 * pad + 1
         raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), dev)
@@ -92,7 +112,7 @@ class _LocalMI(torch.autograd.Function):
             if len(grp) == len(ctx.windows):
                 gwin, ggrad, gscale = win, grad_raw, scale
             else:
-                idx = torch.tensor(grp, dtype=torch.long, device=x.device)
+                idx = cached_const(("idx", str(x.device), tuple(grp)), lambda: torch.tensor(grp, dtype=torch.long, device=x.device))
                 gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[idx].contiguous(), scale[idx].contiguous()
             px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
             tt = (2 * ctx.pad + 1) ** 2

@@ -144,7 +144,9 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         lb, ub = len(labeled_image), len(unlabeled_image)
         with FixRandomSeed(seed):  # same draws, same order as the per-sample flips at ref :148-149
             decisions = self._affine_transformer.decisions(ub)
-        flips = ops.flips_to_tensor(decisions, labeled_image.device)
+        # one host->device copy: [flips of the UB unlabeled samples | UB zeros] (the tf branch is never re-flipped)
+        self._flips2 = ops.flips_to_tensor(list(decisions) + [[False, False]] * ub, labeled_image.device)
+        flips = self._flips2[:ub]
         unlabeled_image_tf = ops.flip(unlabeled_image, flips)
         assert unlabeled_image_tf.shape == unlabeled_image.shape
 
@@ -260,12 +262,13 @@ class IICTrainEpocher(TrainEpocher):
 
     def _iic(self, flips: Tensor, ub: int) -> Tensor:
         dev = flips.device
-        no_flip = torch.zeros_like(flips)
+        flips2 = self._flips2 if getattr(self, "_flips2", None) is not None and len(self._flips2) == 2 * ub \
+            else torch.cat([flips, torch.zeros_like(flips)])
         losses = []
         for feature, projector, criterion in zip(self._fextractor, self._projectors_wrapper, self._IIDSegCriterionWrapper):
             total = feature.shape[0]
             # last 2*UB samples of the tap: [features(unlabeled) | features(flip(unlabeled))]   (ref :258-259)
-            src = torch.arange(total - 2 * ub, total, dtype=torch.int32, device=dev)
+            src = ops.arange_i32(total - 2 * ub, total, dev)
             if isinstance(projector, ClusterHead):  # encoder tap: global pooling is flip-invariant (ref :261-262)
                 probs = projector.forward_gathered(feature, src)                       # [S, 2UB, K]
                 if _DEBUG_ASSERTS:
@@ -274,7 +277,7 @@ class IICTrainEpocher(TrainEpocher):
                 per_head, _, _ = ops.global_mi(probs[:, :ub], probs[:, ub:], criterion.lamb)
                 losses.append(per_head.mean())
             else:  # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
-                probs = projector.forward_gathered(feature, src, torch.cat([flips, no_flip]))  # [S, 2UB, K, H, W]
+                probs = projector.forward_gathered(feature, src, flips2)  # [S, 2UB, K, H, W]
                 per_head = [criterion(p[:ub], p[ub:]) for p in probs]
                 losses.append(average_iter(per_head))
         reg_loss = weighted_average_iter(losses, self._feature_importance)
