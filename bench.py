@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--ub", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--mi-precision", default=None, choices=["fp32", "bf16x3", "bf16"],
+                    help="local-MI contraction arithmetic (default: bf16x3 with --dtype bfloat16, fp32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -113,12 +115,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    from miseg_amd import _cabi, ddp
+    from miseg_amd import _cabi, ddp, ops
     _cabi.lib()
+    mi_prec = args.mi_precision or ("bf16x3" if args.dtype == "bfloat16" else "fp32")
+    ops.set_mi_precision(mi_prec)
     distributed = ddp.init_from_env("nccl")
 
     ep, opt = build_step(device, args.lb, args.ub, args.size, args.dtype, rank)
@@ -167,14 +171,15 @@ def main():
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
                                    f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
-                       "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
+                       "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
                        "parallelism": f"dp{world}"},
         }
         if timer is not None:
             summ = timer.summary()
             table = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])
             name, top = table[0]
-            mfma_f32 = name.startswith(("iic_local", "conv3x3_wgrad", "head_local_bwd")) or args.dtype == "float32"
+            mfma_f32 = name.startswith(("iic_local_bwd", "head_local_bwd")) or args.dtype == "float32" or \
+                (name.startswith("iic_local_joint") and mi_prec == "fp32")
             tf = top["flops_per_call"] / (top["avg_ms"] * 1e-3) / 1e12
             peak = PEAK["mfma_f32"] if mfma_f32 else PEAK["mfma_bf16"]
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",

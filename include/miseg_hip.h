@@ -53,6 +53,8 @@ const char* miseg_last_error(void);
  * reference iteration order; each window is treated as an independent zero-padded map exactly
  * like the reference's crop (:158) followed by conv2d(padding=pad) (:123).  mask: fp32 [N,1,H,W]
  * or NULL (:115-117).
+ * precision : 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32); 1 = bf16 MFMA with hi/lo operand split (3 products,
+ *             fp32-class accuracy); 2 = plain bf16 operands.  1/2 fall back to 0 for shapes the bf16 kernels do not cover.
  * joint_fwd : raw[P][T][T][K][K] (T = 2*pad+1), raw[p][a][b][i][j] =
  *             sum_{n,h,w} Xpad[n,i,h+a,w+b] * Y[n,j,h,w]              (the conv2d at :120-123)
  * loss_fwd  : per window: global-min shift +1e-16 (:124), per-displacement normalise (:129),
@@ -67,7 +69,7 @@ const char* miseg_last_error(void);
 int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P);
 int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, const float* mask, int64_t N,
                               int64_t K, int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
-                              float* raw, void* ws, int64_t ws_bytes);
+                              float* raw, void* ws, int64_t ws_bytes, int precision);
 int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
                              float* loss, float* grad_raw);
 int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,

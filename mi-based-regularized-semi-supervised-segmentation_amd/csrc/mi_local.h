@@ -1,0 +1,69 @@
+// Shared geometry of the local-MI joint kernels (fp32 and bf16 paths).
+#pragma once
+#include "common.h"
+
+namespace miseg {
+
+constexpr int kThreads = 256;         // 4 waves, one per SIMD: each wave owns a full D accumulator
+constexpr int kLdsBudget = 156 * 1024;
+
+struct JointGeom {
+    int N, K, H, W, pad, T, Mdim;
+    int RB, WB, RW;          // block tile rows / cols, rows per wave
+    int WX, RBY;             // X tile width (WB+2pad), Y tile rows (RB+2pad)
+    int planeX, planeY;      // LDS floats per channel plane (odd => conflict-poor gathers)
+    int P, G;                // windows, persistent blocks per (window, sub-block)
+    int tilesM, sb, tps;     // 16-row tiles of D, sub-blocks per dim, tiles per sub-block
+};
+
+constexpr int kJT = 512;
+
+template <int MT, int NT, int ROLE>
+struct TileSet {
+    static constexpr int SPLIT = (MT * NT + 1) / 2;
+    static constexpr bool mine(int m, int n) { return ((m * NT + n) < SPLIT) == (ROLE == 0); }
+    static constexpr bool row_used(int m) {
+        for (int n = 0; n < NT; ++n)
+            if (mine(m, n)) return true;
+        return false;
+    }
+    static constexpr bool col_used(int n) {
+        for (int m = 0; m < MT; ++m)
+            if (mine(m, n)) return true;
+        return false;
+    }
+};
+
+static inline bool plan_joint(JointGeom& g, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
+    g.N = (int)N; g.K = (int)K; g.H = (int)H; g.W = (int)W; g.pad = (int)pad; g.T = 2 * (int)pad + 1;
+    g.Mdim = g.T * g.K; g.P = (int)P;
+    g.tilesM = (g.Mdim + 15) / 16;
+    const int cap = g.tilesM <= 4 ? 4 : 9;
+    g.sb = (g.tilesM + cap - 1) / cap;
+    g.tps = (g.tilesM + g.sb - 1) / g.sb;
+    static const int cand[][2] = {{8, 64}, {4, 64}, {4, 32}, {4, 16}};
+    bool ok = false;
+    for (auto& c : cand) {
+        g.RB = c[0]; g.WB = c[1]; g.RW = g.RB / 4;
+        g.WX = g.WB + 2 * g.pad; g.RBY = g.RB + 2 * g.pad;
+        g.planeX = (g.RB * g.WX) | 1; g.planeY = (g.RBY * g.WB) | 1;
+        size_t tiles = (size_t)g.K * (g.planeX + g.planeY) * 4, dred = (size_t)(cap * 16) * (cap * 16) * 4;
+        if (tiles <= (size_t)kLdsBudget && dred <= (size_t)kLdsBudget) { ok = true; break; }
+    }
+    int slots = g.P * g.sb * g.sb;
+    g.G = 256 / slots;
+    if (g.G < 1) g.G = 1;
+    return ok;
+}
+static inline size_t joint_lds_bytes(const JointGeom& g) {
+    int cap = g.tilesM <= 4 ? 4 : 9;
+    size_t tiles = (size_t)g.K * (g.planeX + g.planeY) * 4, dred = (size_t)(cap * 16) * (cap * 16) * 4;
+    return tiles > dred ? tiles : dred;
+}
+
+
+int launch_joint_fwd_bf16(hipStream_t st, const float* x, const float* y, const float* mask, const JointGeom& g, const int32_t* win,
+                          float* partials, int nterms);
+bool joint_fwd_bf16_supported(const JointGeom& g);
+
+}  // namespace miseg

@@ -12,44 +12,14 @@
 // (20/32)^2 of a per-displacement 20x20 tile) and no im2col copy is ever materialised: operand
 // fragments are gathered straight from haloed LDS tiles of X and Y.
 // This file is the exact-fp32 path: v_mfma_f32_16x16x4_f32 (k-ordered fp32 fma chain).
-#include "common.h"
+#include "mi_local.h"
 
 namespace miseg {
-
-constexpr int kThreads = 256;         // 4 waves, one per SIMD: each wave owns a full D accumulator
-constexpr int kLdsBudget = 156 * 1024;
-
-struct JointGeom {
-    int N, K, H, W, pad, T, Mdim;
-    int RB, WB, RW;          // block tile rows / cols, rows per wave
-    int WX, RBY;             // X tile width (WB+2pad), Y tile rows (RB+2pad)
-    int planeX, planeY;      // LDS floats per channel plane (odd => conflict-poor gathers)
-    int P, G;                // windows, persistent blocks per (window, sub-block)
-    int tilesM, sb, tps;     // 16-row tiles of D, sub-blocks per dim, tiles per sub-block
-};
 
 // D[(dx,i),(dy,j)] accumulators: MT x NT tiles of 16x16 (4 fp32 per lane each).  A full 9x9 D is 324
 // registers per lane -- more than the 256-entry accumulator file -- so the D tile set is split between
 // the two waves of a PAIR (role 0 / role 1, 41 + 40 tiles for 9x9) that sweep the same image rows;
 // a block is 4 pairs = 8 waves (2 per SIMD) sharing one staged X/Y tile.
-constexpr int kJT = 512;
-
-template <int MT, int NT, int ROLE>
-struct TileSet {
-    static constexpr int SPLIT = (MT * NT + 1) / 2;
-    static constexpr bool mine(int m, int n) { return ((m * NT + n) < SPLIT) == (ROLE == 0); }
-    static constexpr bool row_used(int m) {
-        for (int n = 0; n < NT; ++n)
-            if (mine(m, n)) return true;
-        return false;
-    }
-    static constexpr bool col_used(int n) {
-        for (int m = 0; m < MT; ++m)
-            if (mine(m, n)) return true;
-        return false;
-    }
-};
-
 template <int MT, int NT, int ROLE>
 __device__ __forceinline__ void joint_fwd_body(const float* __restrict__ x, const float* __restrict__ y,
                                                const float* __restrict__ mask, const JointGeom& g,
@@ -189,33 +159,6 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const float* __restri
         const int sm = m / (g.tps * 16), sn = c / (g.tps * 16);
         return ((size_t)((p * g.sb + sm) * g.sb + sn) * g.G) * Dsz + (size_t)(m - sm * g.tps * 16) * Dn + (c - sn * g.tps * 16);
     });
-}
-
-static bool plan_joint(JointGeom& g, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
-    g.N = (int)N; g.K = (int)K; g.H = (int)H; g.W = (int)W; g.pad = (int)pad; g.T = 2 * (int)pad + 1;
-    g.Mdim = g.T * g.K; g.P = (int)P;
-    g.tilesM = (g.Mdim + 15) / 16;
-    const int cap = g.tilesM <= 4 ? 4 : 9;
-    g.sb = (g.tilesM + cap - 1) / cap;
-    g.tps = (g.tilesM + g.sb - 1) / g.sb;
-    static const int cand[][2] = {{8, 64}, {4, 64}, {4, 32}, {4, 16}};
-    bool ok = false;
-    for (auto& c : cand) {
-        g.RB = c[0]; g.WB = c[1]; g.RW = g.RB / 4;
-        g.WX = g.WB + 2 * g.pad; g.RBY = g.RB + 2 * g.pad;
-        g.planeX = (g.RB * g.WX) | 1; g.planeY = (g.RBY * g.WB) | 1;
-        size_t tiles = (size_t)g.K * (g.planeX + g.planeY) * 4, dred = (size_t)(cap * 16) * (cap * 16) * 4;
-        if (tiles <= (size_t)kLdsBudget && dred <= (size_t)kLdsBudget) { ok = true; break; }
-    }
-    int slots = g.P * g.sb * g.sb;
-    g.G = 256 / slots;
-    if (g.G < 1) g.G = 1;
-    return ok;
-}
-static size_t joint_lds_bytes(const JointGeom& g) {
-    int cap = g.tilesM <= 4 ? 4 : 9;
-    size_t tiles = (size_t)g.K * (g.planeX + g.planeY) * 4, dred = (size_t)(cap * 16) * (cap * 16) * 4;
-    return tiles > dred ? tiles : dred;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -634,7 +577,7 @@ extern "C" int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t 
 
 extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, const float* mask, int64_t N,
                                          int64_t K, int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
-                                         float* raw, void* ws, int64_t ws_bytes) {
+                                         float* raw, void* ws, int64_t ws_bytes, int precision) {
     MISEG_REQUIRE(x && y && win && raw && ws, "iic_local_joint_fwd: null pointer");
     MISEG_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_joint_fwd: bad shape");
     JointGeom g;
@@ -645,7 +588,9 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
     dim3 grid(g.G, g.P * g.sb * g.sb), block(kJT);
     hipStream_t st = as_stream(stream);
     const int cap = g.tilesM <= 4 ? 4 : 9;
-    if (cap == 4) {
+    if (precision != 0 && mask == nullptr && joint_fwd_bf16_supported(g)) {   // 1: bf16 x3 split (fp32-class), 2: plain bf16
+        launch_joint_fwd_bf16(st, x, y, mask, g, win, (float*)ws, precision == 1 ? 3 : 1);
+    } else if (cap == 4) {
         hipFuncSetAttribute((const void*)joint_fwd_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL((joint_fwd_kernel<4, 4>), grid, block, ldsb, st, x, y, mask, g, win, (float*)ws);
     } else {

@@ -26,8 +26,12 @@ from .flat import FlatBuffers
 def init_from_env(backend: Optional[str] = None) -> bool:
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns True if world_size > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get("MISEG_FORCE_DDP", "0") != "1":  # FORCE: exercise the RCCL path with one rank
         return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -61,6 +61,17 @@ def flips_to_tensor(decisions: Sequence[Sequence[bool]], device) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------ local MI
+MI_PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+_mi_precision = MI_PRECISIONS.get(__import__("os").environ.get("MISEG_MI_PRECISION", "fp32"), 0)
+
+
+def set_mi_precision(mode: str) -> None:
+    """Arithmetic of the local-MI contraction: 'fp32' (exact fp32 MFMA, default), 'bf16x3' (bf16 MFMA on hi/lo-split
+    operands: fp32-class accuracy at 3/16 of the MFMA time) or 'bf16' (plain bf16 operands)."""
+    global _mi_precision
+    _mi_precision = MI_PRECISIONS[mode]
+
+
 def colour_windows(windows: Sequence[Tuple[int, int, int, int]]) -> List[List[int]]:
     """Greedy colouring of overlapping windows into pairwise-disjoint groups (deterministic backward:
     each group is one launch with plain read-modify-write, groups run in stream order)."""
@@ -92,7 +103,8 @@ class _LocalMI(torch.autograd.Function):
         ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), dev)
         px = sum((a1 - a0) * (b1 - b0) for a0, a1, b0, b1 in windows)
         call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
-             _ptr(ws), ws.numel(), work=(2.0 * k * k * t * t * n * px, 2.0 * n * k * px * 4), tag=f"iic_local_joint_fwd[p{pad}]")
+             _ptr(ws), ws.numel(), _mi_precision, work=(2.0 * k * k * t * t * n * px, 2.0 * n * k * px * 4),
+             tag=f"iic_local_joint_fwd[p{pad}]")
         loss = torch.empty(p, dtype=torch.float32, device=dev)
         grad_raw = torch.empty_like(raw)
         call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
@@ -126,7 +138,7 @@ def local_mi_losses(x: Tensor, y: Tensor, pad: int, windows, lamda: float = 1.0,
     return _LocalMI.apply(x, y, mask, int(pad), [tuple(int(v) for v in w) for w in windows], float(lamda))
 
 
-def local_mi_raw_joint(x: Tensor, y: Tensor, pad: int, windows, mask: Optional[Tensor] = None) -> Tensor:
+def local_mi_raw_joint(x: Tensor, y: Tensor, pad: int, windows, mask: Optional[Tensor] = None, precision: Optional[str] = None) -> Tensor:
     """raw[P][T][T][K][K] only (no autograd) -- exposed for parity tests of the contraction."""
     _need_gpu(x, y, mask)
     x, y = x.contiguous().float(), y.contiguous().float()
@@ -137,7 +149,7 @@ def local_mi_raw_joint(x: Tensor, y: Tensor, pad: int, windows, mask: Optional[T
     raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=x.device)
     ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), x.device)
     call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
-         _ptr(ws), ws.numel())
+         _ptr(ws), ws.numel(), _mi_precision if precision is None else MI_PRECISIONS[precision])
     return raw
 
 
