@@ -74,7 +74,9 @@ int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t 
                              float* loss, float* grad_raw);
 int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
                         int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
-                        const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate);
+                        const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate, int precision,
+                        void* ws, int64_t ws_bytes);
+int64_t miseg_iic_local_bwd_ws_bytes(int64_t K, int64_t pad, int64_t P);
 
 /* ------------------------------------------------------------------------------------------
  * Global IIC mutual information, S sub-heads in one launch

@@ -65,5 +65,10 @@ static inline size_t joint_lds_bytes(const JointGeom& g) {
 int launch_joint_fwd_bf16(hipStream_t st, const float* x, const float* y, const float* mask, const JointGeom& g, const int32_t* win,
                           float* partials, int nterms);
 bool joint_fwd_bf16_supported(const JointGeom& g);
+bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad);
+size_t local_bwd_bf16_ws_bytes(int64_t K, int64_t pad, int64_t P);
+int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
+                          const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
+                          void* ws, int nterms);
 
 }  // namespace miseg

@@ -604,6 +604,10 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
     return MISEG_OK;
 }
 
+extern "C" int64_t miseg_iic_local_bwd_ws_bytes(int64_t K, int64_t pad, int64_t P) {
+    return (int64_t)local_bwd_bf16_ws_bytes(K, pad, P) + 16;
+}
+
 extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
                                         float* loss, float* grad_raw) {
     MISEG_REQUIRE(raw && loss && grad_raw, "iic_local_loss_fwd: null pointer");
@@ -620,10 +624,17 @@ extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t 
 
 extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
                                    int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw,
-                                   const float* scale, float* gx, float* gy, int accumulate) {
+                                   const float* scale, float* gx, float* gy, int accumulate, int precision,
+                                   void* ws, int64_t ws_bytes) {
     MISEG_REQUIRE(x && y && win && grad_raw && scale && gx && gy, "iic_local_bwd: null pointer");
     MISEG_REQUIRE(N > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_bwd: bad shape (K<=32)");
     hipStream_t st = as_stream(stream);
+    if (precision != 0 && mask == nullptr && local_bwd_bf16_supported(N, K, H, W, pad)) {   // bf16 MFMA, hi/lo split (1) or plain (2)
+        MISEG_REQUIRE(ws && ws_bytes >= (int64_t)local_bwd_bf16_ws_bytes(K, pad, P), "iic_local_bwd: workspace too small for the bf16 path");
+        launch_local_bwd_bf16(st, x, y, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, precision == 1 ? 3 : 1);
+        MISEG_LAUNCH_CHECK("local_bwd_bf16_kernel");
+        return MISEG_OK;
+    }
     {   // fast path: transposed GEMM + LDS col2im (needs T*K <= 144 rows and the G matrix + tiles in LDS)
         Bwd2Geom b2;
         b2.N = (int)N; b2.K = (int)K; b2.Kc = ((int)K + 3) & ~3; b2.H = (int)H; b2.W = (int)W; b2.pad = (int)pad; b2.T = 2 * (int)pad + 1;

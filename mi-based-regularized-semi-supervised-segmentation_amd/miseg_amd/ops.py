@@ -120,6 +120,7 @@ class _LocalMI(torch.autograd.Function):
         whole = len(ctx.windows) == 1 and tuple(ctx.windows[0]) == (0, h, 0, w)
         gx, gy = (torch.empty_like(x), torch.empty_like(y)) if whole else (torch.zeros_like(x), torch.zeros_like(y))
         scale = gloss.contiguous().float()
+        bws = _ws(query("miseg_iic_local_bwd_ws_bytes", k, ctx.pad, len(ctx.windows)), x.device)
         for grp in colour_windows(ctx.windows):
             if len(grp) == len(ctx.windows):
                 gwin, ggrad, gscale = win, grad_raw, scale
@@ -129,7 +130,7 @@ class _LocalMI(torch.autograd.Function):
             px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
             tt = (2 * ctx.pad + 1) ** 2
             call("miseg_iic_local_bwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, ctx.pad, _ptr(gwin), len(grp),
-                 _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy), 0 if whole else 1, work=(4.0 * k * k * tt * n * px, 4.0 * n * k * px * 4),
+                 _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(), work=(4.0 * k * k * tt * n * px, 4.0 * n * k * px * 4),
                  tag=f"iic_local_bwd[p{ctx.pad}]")
         return gx, gy, None, None, None, None
 

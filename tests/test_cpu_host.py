@@ -39,7 +39,7 @@ def test_host_side_argument_validation_without_gpu():
     with pytest.raises(_cabi.MisegError):
         _cabi.query("miseg_iic_local_joint_ws_bytes", 16, 20, 256, 256, 3, 0)        # P must be > 0
     with pytest.raises(_cabi.MisegError, match="null pointer"):
-        _cabi.call("miseg_iic_local_joint_fwd", None, None, None, None, 1, 1, 1, 1, 0, None, 1, None, None, 0)
+        _cabi.call("miseg_iic_local_joint_fwd", None, None, None, None, 1, 1, 1, 1, 0, None, 1, None, None, 0, 0)
 
 
 def test_product_refuses_cpu_tensors():

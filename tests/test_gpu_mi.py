@@ -203,3 +203,26 @@ def test_joint_bf16_split_matches_fp32_kernel(n, k, h, w, p):
             e_split = float((split[0].double().cpu() - truth).abs().max())
             e_ref = float((ref[0].double().cpu() - truth).abs().max())
             assert e_split <= 4 * e_ref + 1e-6 * scale, (e_split, e_ref)
+
+
+@pytest.mark.parametrize("n,h,w,p", [(4, 32, 32, 3), (4, 32, 32, 1), (3, 70, 90, 3)])
+def test_local_mi_bf16_split_fwd_bwd_matches_fp64(n, h, w, p):
+    """Whole local-MI op (joint -> loss -> backward) in 'bf16x3' precision vs the fp64 oracle: same bounds as the fp32 path."""
+    k = 20
+    gen = torch.Generator(device="cpu").manual_seed(n * 100 + h + p)
+    x0 = torch.randn(n, k, h, w, generator=gen).softmax(1)
+    y0 = torch.randn(n, k, h, w, generator=gen).softmax(1)
+    x64, y64 = x0.double().requires_grad_(True), y0.double().requires_grad_(True)
+    truth = OI.iid_seg_loss(x64, y64, p)
+    gx64, gy64 = torch.autograd.grad(truth, [x64, y64])
+    ops().set_mi_precision("bf16x3")
+    try:
+        x, y = x0.to(DEV).requires_grad_(True), y0.to(DEV).requires_grad_(True)
+        loss = ops().local_mi_losses(x, y, p, [(0, h, 0, w)])[0]
+        loss.backward()
+    finally:
+        ops().set_mi_precision("fp32")
+    assert abs(float(loss) - float(truth)) <= 5e-7, (float(loss), float(truth))
+    gscale = float(gx64.abs().max())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gx64.numpy(), rtol=0, atol=2e-4 * gscale + 1e-12)
+    np.testing.assert_allclose(y.grad.cpu().numpy(), gy64.numpy(), rtol=0, atol=2e-4 * gscale + 1e-12)
