@@ -178,8 +178,10 @@ def main():
             summ = timer.summary()
             table = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])
             name, top = table[0]
-            mfma_f32 = name.startswith(("iic_local_bwd", "head_local_bwd")) or args.dtype == "float32" or \
-                (name.startswith("iic_local_joint") and mi_prec == "fp32")
+            # which matrix pipe the kernel runs on: local-MI follows --mi-precision (bf16x3 = three bf16 MFMAs per
+            # algorithmic product, priced against the plain bf16 dense peak), head backward is fp32 MFMA, convs follow --dtype
+            mfma_f32 = name.startswith("head_local_bwd") or (name.startswith("iic_local") and mi_prec == "fp32") or \
+                (name.startswith("conv3x3") and args.dtype == "float32")
             tf = top["flops_per_call"] / (top["avg_ms"] * 1e-3) / 1e12
             peak = PEAK["mfma_f32"] if mfma_f32 else PEAK["mfma_bf16"]
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
