@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restri
 //   phase 2 (fp32 MFMA):       gfeat[px][c] = sum_(s,k) dz[(s,k)][px] * W[(s,k)][c]     (M=px, N=c, Kred=S*K)
 //   phase 3 (fp32 MFMA):       gw[(s,k)][c] += sum_px dz[(s,k)][px] * f[px][c]          (M=(s,k), N=c, Kred=px)
 // gw / gb accumulate in registers across the block's chunks; one deterministic partial per block at the end.
-template <typename T, int CTM>
-__global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
+template <typename T, int CTM, int RW>
+__global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                    int M, const float* __restrict__ w, int S, int K, float invT,
                                                                    const float* __restrict__ prob, const float* __restrict__ gprob,
@@ -209,10 +209,12 @@ __global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __re
     extern __shared__ float sm[];
     const int R = S * K, RT = (R + 15) / 16, RP = RT * 16, CT = (C + 15) / 16, HW = H * W;
     constexpr int DZS = 65;
+    constexpr int FPT = CTM * 4;              // feature values per thread: 64 px * (CTM*16) channels / 256 threads
     const int FS = C + 1, WS = C + 1;
-    float* dzs = sm;                          // [RP][DZS]   dz, rows >= R zero
+    float* dzs = sm;                          // [RP][DZS]   p*g, then dz; rows >= R zero
     float* fs = dzs + (size_t)RP * DZS;       // [64][FS]    feature chunk (fp32)
     float* wsm = fs + (size_t)64 * FS;        // [RP][WS]    head weights, rows >= R zero
+    float* dots = wsm + (size_t)RP * WS;      // [S][64]     <g,p> per (sub-head, pixel)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     for (int idx = tid; idx < RP * C; idx += 256) {
         const int c = idx % C, r = idx / C;
@@ -227,39 +229,81 @@ __global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __re
     float gbacc = 0.f;
     const int chunksPerM = (HW + 63) / 64;
     const int64_t nchunks = (int64_t)M * chunksPerM;
+    const uint32_t kmagic = (65536u + (uint32_t)K - 1u) / (uint32_t)K;   // r / K == (r * kmagic) >> 16 for r*K < 65536
+    const int px = lane;
+    // Rows r = wv + 4i of (s,k) belong to wave wv: every wave streams ~R/4 coalesced 256-byte row segments of prob and
+    // gprob per chunk.  The chunk's values live in registers and are fetched one chunk ahead (issued before the MFMA
+    // phases of the current chunk), so the HBM latency hides behind phases 2/3.
+    float pr[RW], gr[RW], fr[FPT];
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);   // wave-uniform: row offsets below stay in SGPRs
+    const size_t tot = (size_t)S * M * K * HW;            // floats in prob / gprob (host checks tot*4 < 2^32)
+    auto fetch = [&](int64_t ch) {
+        const int m = ch / chunksPerM, p0 = (ch % chunksPerM) * 64;
+        const bool live = p0 + px < HW;
+        const int pxc = live ? px : 0;
+        // one buffer resource per chunk (uniform base), row offsets as scalar soffsets, px as the only VGPR offset
+        const size_t boff = (size_t)m * K * HW + p0;
+        const uint32_t rem = (uint32_t)((tot - boff) * 4);
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(prob + boff), 0, (int)rem, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gprob + boff), 0, (int)rem, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int r = min(wvu + 4 * i, R - 1);   // rows past R re-read row R-1 (branch-free issue); never stored
+            const int sidx = (int)(((uint32_t)r * kmagic) >> 16);
+            const uint32_t so = ((uint32_t)r + (uint32_t)sidx * (uint32_t)(M - 1) * (uint32_t)K) * (uint32_t)HW * 4u;
+            const float pv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pxc * 4, (int)so, 0));
+            const float gv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, pxc * 4, (int)so, 0));
+            pr[i] = live ? pv : 0.f;
+            gr[i] = live ? gv : 0.f;
+        }
+        const int f = flips ? flips[m] : 0;
+        const size_t fb = (size_t)src[m] * HW;
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) {
+            const int idx = tid + 256 * j, c = idx % C, q = idx / C;
+            float v = 0.f;
+            if (idx < 64 * C && p0 + q < HW) {
+                const int pq = p0 + q, h = pq / W, wq = pq % W;
+                v = to_f32(feat[(fb + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c]);
+            }
+            fr[j] = v;
+        }
+    };
+    if ((int64_t)blockIdx.x < nchunks) fetch(blockIdx.x);
     for (int64_t ch = blockIdx.x; ch < nchunks; ch += nblk) {
         const int m = ch / chunksPerM, p0 = (ch % chunksPerM) * 64;
         const int f = flips ? flips[m] : 0;
-        const int px = lane, pix = p0 + px;
-        const bool live = pix < HW;
+        __syncthreads();   // previous chunk's MFMA phases are done with dzs / fs
+        // ---- phase 1: dz = p*(g - <g,p>)/T
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int r = wvu + 4 * i;
+            if (r < R) dzs[r * DZS + px] = pr[i] * gr[i];
+        }
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < 64 * C) fs[(idx / C) * FS + idx % C] = fr[j];
+        }
         __syncthreads();
-        // ---- phase 1: dz for sub-heads s = wv, wv+4, ...
-        for (int s = wv; s < S; s += 4) {
-            const size_t base = (((size_t)s * M + m) * K) * HW + pix;
+        for (int sidx = wv; sidx < S; sidx += 4) {
             float dot = 0.f;
-            for (int k = 0; k < K; ++k) {
-                const float pv = live ? prob[base + (size_t)k * HW] : 0.f, gv = live ? gprob[base + (size_t)k * HW] : 0.f;
-                dzs[(s * K + k) * DZS + px] = pv;
-                dot += pv * gv;
-            }
-            for (int k = 0; k < K; ++k) {
-                const float pv = dzs[(s * K + k) * DZS + px], gv = live ? gprob[base + (size_t)k * HW] : 0.f;
-                dzs[(s * K + k) * DZS + px] = pv * (gv - dot) * invT;
-            }
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) dot += dzs[(sidx * K + k) * DZS + px];
+            dots[sidx * 64 + px] = dot;
         }
-        // feature chunk (flip-aware gather), one pixel row of C channels per thread-iteration
-        for (int idx = tid; idx < 64 * C; idx += 256) {
-            const int c = idx % C, q = idx / C;
-            float v = 0.f;
-            if (p0 + q < HW) {
-                const int pq = p0 + q, h = pq / W, wq = pq % W;
-                v = to_f32(feat[((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c]);
-            }
-            fs[q * FS + c] = v;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int r = wvu + 4 * i;
+            const int sidx = (int)(((uint32_t)r * kmagic) >> 16);
+            if (r < R) dzs[r * DZS + px] = pr[i] * (gr[i] - dots[sidx * 64 + px]) * invT;
         }
+        if (ch + nblk < nchunks) fetch(ch + nblk);
         __syncthreads();
         if (tid < R) {
             float a = 0.f;
+#pragma unroll 8
             for (int q = 0; q < 64; ++q) a += dzs[tid * DZS + q];
             gbacc += a;
         }
@@ -268,6 +312,7 @@ __global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __re
             f32x4 accf[CTM];
 #pragma unroll
             for (int c = 0; c < CTM; ++c) accf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int ks = 0; ks < RP; ks += 4) {
                 const float av = dzs[(ks + kq) * DZS + wv * 16 + l15];
 #pragma unroll
@@ -293,6 +338,7 @@ __global__ __launch_bounds__(256) void head_local_bwd_fused_kernel(const T* __re
             }
         }
         // ---- phase 3: gw += dz * f
+#pragma unroll 2
         for (int ks = 0; ks < 64; ks += 4) {
             float bfr[CTM];
 #pragma unroll
@@ -369,23 +415,26 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     MISEG_REQUIRE(feat && src && w && prob && gprob && gw && gb && ws, "head_local_bwd: null pointer");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 128 && K > 0 && K <= 64 && S * K <= 256 && M > 0, "head_local_bwd: need C%%4==0, C<=128, S*K<=256");
     MISEG_REQUIRE(ws_bytes >= miseg_head_local_bwd_ws_bytes(M, H, W, C, S, K), "head_local_bwd: workspace too small");
+    MISEG_REQUIRE(S * M * K * H * W * 4 < ((int64_t)1 << 32), "head_local_bwd: prob larger than 4 GiB (32-bit buffer offsets)");
     hipStream_t st = as_stream(stream);
     float* partials = (float*)ws;
     const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16, RP = RT * 16;
-    const size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1)) * 4;
+    const size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1) + (size_t)S * 64) * 4;
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
-#define HLB(TT, CTM)                                                                                                              \
+#define HLB2(TT, CTM, RW)                                                                                                         \
     {                                                                                                                             \
-        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
-                           src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);                \
+        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
+                           src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);            \
     }
+#define HLB(TT, CTM) { if (R <= 112) HLB2(TT, CTM, 28) else HLB2(TT, CTM, 64) }
 #define HLB_C(TT) { if (C <= 16) HLB(TT, 1) else if (C <= 32) HLB(TT, 2) else if (C <= 64) HLB(TT, 4) else HLB(TT, 8) }
     if (dt == MISEG_F32) HLB_C(float)
     else if (dt == MISEG_BF16) HLB_C(bf16)
     else return fail(MISEG_E_INVALID, "head_local_bwd: bad dtype %d", dt);
 #undef HLB_C
 #undef HLB
+#undef HLB2
     MISEG_LAUNCH_CHECK("head_local_bwd_fused_kernel");
     const int len = R * (int)C + R;
     float* red = partials + (size_t)nblk * len;
