@@ -146,6 +146,11 @@ int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, in
 int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
                       int64_t C, int64_t* pred, int64_t* inter, int64_t* uni);
 
+/* counts the positions of x[outer][C][inner] (fp32) whose channel sum is not within tol of 1 (NaN counts): the device
+ * half of `simplex` (ref whl:deepclustering2/utils/general.py simplex = allclose(sum(axis), 1)); adds into *count. */
+int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_t C, int64_t inner, float tol,
+                             int32_t* count);
+
 /* ------------------------------------------------------------------------------------------
  * U-Net building blocks   ref: contrastyou/arch/unet.py:10-40, 86-133
  * Weights arrive in the reference's OIHW fp32 layout and are re-packed per call into the

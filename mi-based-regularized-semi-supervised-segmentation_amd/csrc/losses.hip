@@ -140,9 +140,36 @@ __global__ __launch_bounds__(256) void argmax_dice_kernel(const float* __restric
 
 static int loss_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv(npix, kLT), 2048); }
 
+// one thread per (outer, inner) position, channel stride = inner: coalesced along inner
+__global__ __launch_bounds__(256) void simplex_violations_kernel(const float* __restrict__ x, int64_t outer, int C, int64_t inner,
+                                                                 float tol, int32_t* __restrict__ count) {
+    const int64_t total = outer * inner;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t o = i / inner, r = i - o * inner;
+        const float* p = x + o * C * inner + r;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += p[(int64_t)c * inner];
+        bad += !(fabsf(s - 1.f) <= tol);
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+
 }  // namespace miseg
 
 using namespace miseg;
+
+extern "C" int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_t C, int64_t inner, float tol,
+                                        int32_t* count) {
+    MISEG_REQUIRE(x && count, "simplex_violations: null pointer");
+    MISEG_REQUIRE(outer > 0 && C > 0 && inner > 0 && C < (1 << 20), "simplex_violations: bad shape");
+    const int64_t total = outer * inner;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(simplex_violations_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, outer, (int)C, inner, tol, count);
+    MISEG_LAUNCH_CHECK("simplex_violations_kernel");
+    return MISEG_OK;
+}
 
 extern "C" int64_t miseg_loss_ws_bytes(int64_t N, int64_t H, int64_t W) { return (int64_t)loss_blocks(N * H * W) * 4; }
 

@@ -1,0 +1,81 @@
+"""Device-side assertions that do not stall the stream.
+
+The reference asserts ``simplex(prob)`` and raises on NaN losses inline (contrastyou/losses/iic_loss.py:28-29,
+102-104,132-133,184-186; whl:deepclustering2/loss/kl_losses.py), each of which is a blocking device->host read.
+Here every check produces a 0-d device tensor (non-zero = failed).  Outside a ``deferred`` block the check is
+evaluated at once (same behaviour as the reference).  Inside one -- the train epocher opens it around an iteration --
+the flags ride along with the iteration's single host copy and the same exception is raised there.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._cabi import call
+
+_Item = Tuple[Tensor, Callable[[str], BaseException], str]
+_active: Optional[List[_Item]] = None
+
+
+class deferred:
+    """``with deferred(items):`` -- checks issued inside are appended to ``items`` instead of being evaluated."""
+
+    def __init__(self, items: List[_Item]):
+        self.items = items
+
+    def __enter__(self):
+        global _active
+        self._prev, _active = _active, self.items
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self._prev
+        return False
+
+
+def require_zero(bad: Tensor, exc, msg: str) -> None:
+    """Fail with ``exc(msg)`` if the 0-d device tensor ``bad`` is non-zero (now, or at the enclosing block's fetch)."""
+    if _active is None:
+        if float(bad) != 0.0:
+            raise exc(msg)
+    else:
+        _active.append((bad.detach().reshape(()).float(), exc, msg))
+
+
+def raise_failed(items: List[_Item], host_flags) -> None:
+    for (_, exc, msg), flag in zip(items, host_flags):
+        if flag != 0.0:
+            raise exc(msg)
+
+
+def simplex_violations(t: Tensor, axis: int = 1, tol: float = 2e-4) -> Tensor:
+    """0-d int32 device count of positions whose sum over ``axis`` is not within tol of 1 (tol = allclose's
+    atol + rtol*1 of the reference's ``simplex``)."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        s = t.float().sum(axis)
+        return (~((s - 1.0).abs() <= tol)).sum().to(torch.int32)
+    t = t.contiguous()
+    axis = axis % t.dim()
+    outer = 1
+    for d in t.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in t.shape[axis + 1:]:
+        inner *= d
+    count = torch.zeros((), dtype=torch.int32, device=t.device)
+    if t.numel():
+        call("miseg_simplex_violations", torch.cuda.current_stream().cuda_stream, t.data_ptr(), outer, t.shape[axis], inner,
+             float(tol), count.data_ptr())
+    return count
+
+
+def assert_simplex(t: Tensor, axis: int = 1, msg: str = "") -> None:
+    require_zero(simplex_violations(t, axis), AssertionError, msg)
+
+
+def raise_if_nan(values: Tensor, describe: str = "nan loss") -> None:
+    """ref iic_loss.py:132-133 / :184-186 raise RuntimeError when a (patch) loss is NaN."""
+    require_zero(torch.isnan(values).sum(), RuntimeError, describe)

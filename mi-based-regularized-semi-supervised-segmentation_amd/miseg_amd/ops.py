@@ -86,6 +86,41 @@ def colour_windows(windows: Sequence[Tuple[int, int, int, int]]) -> List[List[in
     return groups
 
 
+def _local_fwd(x: Tensor, y: Tensor, mask, pad: int, windows, win: Tensor, raw: Tensor) -> None:
+    """raw[P][T][T][K][K] of one (x, y) pair: both contiguous [N,K,H,W] fp32 (possibly views into a larger tensor)."""
+    n, k, h, w = x.shape
+    p, t = len(windows), 2 * pad + 1
+    ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), x.device)
+    px = sum((a1 - a0) * (b1 - b0) for a0, a1, b0, b1 in windows)
+    call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
+         _ptr(ws), ws.numel(), _mi_precision, work=(2.0 * k * k * t * t * n * px, 2.0 * n * k * px * 4),
+         tag=f"iic_local_joint_fwd[p{pad}]")
+
+
+def _is_whole(windows, h: int, w: int) -> bool:
+    return len(windows) == 1 and tuple(windows[0]) == (0, h, 0, w)
+
+
+def _local_bwd(x: Tensor, y: Tensor, mask, pad: int, windows, win: Tensor, grad_raw: Tensor, scale: Tensor, gx: Tensor,
+               gy: Tensor) -> None:
+    """gx, gy (same layout as x, y): overwritten for a single whole-image window, accumulated into otherwise (caller
+    zero-fills).  Overlapping windows are split into disjoint colour groups, one launch each, in stream order."""
+    n, k, h, w = x.shape
+    whole = _is_whole(windows, h, w)
+    bws = _ws(query("miseg_iic_local_bwd_ws_bytes", k, pad, len(windows)), x.device)
+    tt = (2 * pad + 1) ** 2
+    for grp in colour_windows(windows):
+        if len(grp) == len(windows):
+            gwin, ggrad, gscale = win, grad_raw, scale
+        else:
+            idx = cached_const(("idx", str(x.device), tuple(grp)), lambda: torch.tensor(grp, dtype=torch.long, device=x.device))
+            gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[idx].contiguous(), scale[idx].contiguous()
+        px = sum((windows[i][1] - windows[i][0]) * (windows[i][3] - windows[i][2]) for i in grp)
+        call("miseg_iic_local_bwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(gwin), len(grp),
+             _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(),
+             work=(4.0 * k * k * tt * n * px, 4.0 * n * k * px * 4), tag=f"iic_local_bwd[p{pad}]")
+
+
 class _LocalMI(torch.autograd.Function):
     """loss[P] of IIDSegmentationLoss over P windows (ref: contrastyou/losses/iic_loss.py:107-149)."""
 
@@ -100,11 +135,7 @@ class _LocalMI(torch.autograd.Function):
         win = windows_tensor(windows, dev)
         t = 2 * pad + 1
         raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=dev)
-        ws = _ws(query("miseg_iic_local_joint_ws_bytes", n, k, h, w, pad, p), dev)
-        px = sum((a1 - a0) * (b1 - b0) for a0, a1, b0, b1 in windows)
-        call("miseg_iic_local_joint_fwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, pad, _ptr(win), p, _ptr(raw),
-             _ptr(ws), ws.numel(), _mi_precision, work=(2.0 * k * k * t * t * n * px, 2.0 * n * k * px * 4),
-             tag=f"iic_local_joint_fwd[p{pad}]")
+        _local_fwd(x, y, mask, pad, windows, win, raw)
         loss = torch.empty(p, dtype=torch.float32, device=dev)
         grad_raw = torch.empty_like(raw)
         call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
@@ -117,22 +148,54 @@ class _LocalMI(torch.autograd.Function):
     def backward(ctx, gloss: Tensor):
         x, y, mask, grad_raw, win = ctx.saved_tensors
         n, k, h, w = x.shape
-        whole = len(ctx.windows) == 1 and tuple(ctx.windows[0]) == (0, h, 0, w)
+        whole = _is_whole(ctx.windows, h, w)
         gx, gy = (torch.empty_like(x), torch.empty_like(y)) if whole else (torch.zeros_like(x), torch.zeros_like(y))
-        scale = gloss.contiguous().float()
-        bws = _ws(query("miseg_iic_local_bwd_ws_bytes", k, ctx.pad, len(ctx.windows)), x.device)
-        for grp in colour_windows(ctx.windows):
-            if len(grp) == len(ctx.windows):
-                gwin, ggrad, gscale = win, grad_raw, scale
-            else:
-                idx = cached_const(("idx", str(x.device), tuple(grp)), lambda: torch.tensor(grp, dtype=torch.long, device=x.device))
-                gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[idx].contiguous(), scale[idx].contiguous()
-            px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
-            tt = (2 * ctx.pad + 1) ** 2
-            call("miseg_iic_local_bwd", _stream(), _ptr(x), _ptr(y), _ptr(mask), n, k, h, w, ctx.pad, _ptr(gwin), len(grp),
-                 _ptr(ggrad), _ptr(gscale), _ptr(gx), _ptr(gy), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(), work=(4.0 * k * k * tt * n * px, 4.0 * n * k * px * 4),
-                 tag=f"iic_local_bwd[p{ctx.pad}]")
+        _local_bwd(x, y, mask, ctx.pad, ctx.windows, win, grad_raw, gloss.contiguous().float(), gx, gy)
         return gx, gy, None, None, None, None
+
+
+class _LocalMIHeads(torch.autograd.Function):
+    """All S sub-heads of one decoder tap in one node: probs[S, 2*UB, K, H, W] holds, per sub-head, the UB maps of the
+    flipped features followed by the UB maps of the transformed image (ref semi_seg/epocher.py:264-272 evaluates the
+    criterion once per sub-head on ``p[:ub], p[ub:]``).  loss[S][P]; the backward writes every sub-head's gradient
+    straight into one gprob[S, 2*UB, K, H, W] buffer, so autograd never materialises per-slice zero-padded copies."""
+
+    @staticmethod
+    def forward(ctx, probs: Tensor, ub: int, mask: Optional[Tensor], pad: int, windows, lamda: float):
+        _need_gpu(probs, mask)
+        probs = probs.contiguous().float()
+        mask = None if mask is None else mask.contiguous().float()
+        s, n2, k, h, w = probs.shape
+        if n2 != 2 * ub:
+            raise _cabi.MisegError(f"local_mi_heads: probs holds {n2} maps per sub-head, expected 2*{ub}")
+        p, t, dev = len(windows), 2 * pad + 1, probs.device
+        win = windows_tensor(windows, dev)
+        raw = torch.empty(s, p, t, t, k, k, dtype=torch.float32, device=dev)
+        for i in range(s):
+            _local_fwd(probs[i, :ub], probs[i, ub:], mask, pad, windows, win, raw[i])
+        loss = torch.empty(s, p, dtype=torch.float32, device=dev)
+        grad_raw = torch.empty_like(raw)
+        call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, s * p, float(lamda), _ptr(loss), _ptr(grad_raw))
+        ctx.save_for_backward(probs, mask, grad_raw, win)
+        ctx.pad, ctx.windows, ctx.ub = pad, list(windows), ub
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss: Tensor):
+        probs, mask, grad_raw, win = ctx.saved_tensors
+        s, _, k, h, w = probs.shape
+        ub = ctx.ub
+        gprob = torch.empty_like(probs) if _is_whole(ctx.windows, h, w) else torch.zeros_like(probs)
+        scale = gloss.contiguous().float()
+        for i in range(s):
+            _local_bwd(probs[i, :ub], probs[i, ub:], mask, ctx.pad, ctx.windows, win, grad_raw[i], scale[i], gprob[i, :ub],
+                       gprob[i, ub:])
+        return gprob, None, None, None, None, None
+
+
+def local_mi_heads(probs: Tensor, ub: int, pad: int, windows, lamda: float = 1.0, mask: Optional[Tensor] = None) -> Tensor:
+    """loss[S][P] for probs[S, 2*UB, K, H, W] (see _LocalMIHeads)."""
+    return _LocalMIHeads.apply(probs, int(ub), mask, int(pad), [tuple(int(v) for v in w) for w in windows], float(lamda))
 
 
 def local_mi_losses(x: Tensor, y: Tensor, pad: int, windows, lamda: float = 1.0, mask: Optional[Tensor] = None) -> Tensor:

@@ -36,7 +36,7 @@ from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterIn
 from deepclustering2.optim import get_lrs_from_optimizer
 from deepclustering2.type import T_loader, T_loss, T_optim
 from deepclustering2.utils import class2one_hot
-from miseg_amd import ops
+from miseg_amd import checks, ops
 from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
 
 _DEBUG_ASSERTS = os.environ.get("MISEG_ASSERTS", "0") == "1"
@@ -56,22 +56,26 @@ class _num_class_mixin:
 
 
 class _Pending:
-    """Device scalars whose host values are fetched with a single synchronising copy per iteration."""
+    """Device scalars whose host values are fetched with a single synchronising copy per iteration; the deferred
+    assertion flags of miseg_amd.checks ride in the same copy and are raised right after it."""
 
     def __init__(self):
         self._names: List[str] = []
         self._vals: List[Tensor] = []
+        self.checks: list = []
 
     def put(self, name: str, value: Tensor) -> None:
         self._names.append(name)
         self._vals.append(value.detach().reshape(()).float())
 
     def fetch(self) -> dict:
-        if not self._vals:
+        if not self._vals and not self.checks:
             return {}
-        host = torch.stack(self._vals).tolist()
+        host = torch.stack(self._vals + [c[0] for c in self.checks]).tolist()
         out = dict(zip(self._names, host))
+        items, self.checks[:] = list(self.checks), []
         self._names, self._vals = [], []
+        checks.raise_failed(items, host[len(out):])
         return out
 
 
@@ -153,18 +157,19 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         predict_logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
         label_logits, unlabel_logits, unlabel_tf_logits = torch.split(predict_logits, [lb, ub, ub], dim=0)
         labels = labeled_target.squeeze(1)
-        if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
-            sup_loss = self._sup_criterion.from_logits(label_logits, labels)
-        else:
-            sup_loss = self._sup_criterion(label_logits.softmax(1), class2one_hot(labels, self.num_classes))
-        reg_fn = self.regularization
-        fused = getattr(reg_fn, "_miseg_fused", False)
-        reg_loss = reg_fn(
-            unlabeled_tf_logits=unlabel_tf_logits,
-            unlabeled_logits_tf=None if fused else ops.flip(unlabel_logits, flips),
-            seed=seed, unlabeled_image=unlabeled_image, unlabeled_image_tf=unlabeled_image_tf,
-            unlabeled_logits=unlabel_logits, flips=flips, num_unlabeled=ub,
-        )
+        with checks.deferred(self._pending.checks):   # simplex / NaN assertions are raised at this iteration's fetch()
+            if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
+                sup_loss = self._sup_criterion.from_logits(label_logits, labels)
+            else:
+                sup_loss = self._sup_criterion(label_logits.softmax(1), class2one_hot(labels, self.num_classes))
+            reg_fn = self.regularization
+            fused = getattr(reg_fn, "_miseg_fused", False)
+            reg_loss = reg_fn(
+                unlabeled_tf_logits=unlabel_tf_logits,
+                unlabeled_logits_tf=None if fused else ops.flip(unlabel_logits, flips),
+                seed=seed, unlabeled_image=unlabeled_image, unlabeled_image_tf=unlabeled_image_tf,
+                unlabeled_logits=unlabel_logits, flips=flips, num_unlabeled=ub,
+            )
         total_loss = sup_loss + self._reg_weight * reg_loss
         self._optimizer.zero_grad()
         if self._reducer is not None:
@@ -278,8 +283,10 @@ class IICTrainEpocher(TrainEpocher):
                 losses.append(per_head.mean())
             else:  # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
                 probs = projector.forward_gathered(feature, src, flips2)  # [S, 2UB, K, H, W]
-                per_head = [criterion(p[:ub], p[ub:]) for p in probs]
-                losses.append(average_iter(per_head))
+                if hasattr(criterion, "forward_heads"):   # all sub-heads as one autograd node (gradient lands in one buffer)
+                    losses.append(criterion.forward_heads(probs, ub).mean())
+                else:
+                    losses.append(average_iter([criterion(p[:ub], p[ub:]) for p in probs]))
         reg_loss = weighted_average_iter(losses, self._feature_importance)
         self._pending.put("mi", -reg_loss)
         for name, v in zip(self._feature_position, losses):

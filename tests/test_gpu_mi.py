@@ -226,3 +226,47 @@ def test_local_mi_bf16_split_fwd_bwd_matches_fp64(n, h, w, p):
     gscale = float(gx64.abs().max())
     np.testing.assert_allclose(x.grad.cpu().numpy(), gx64.numpy(), rtol=0, atol=2e-4 * gscale + 1e-12)
     np.testing.assert_allclose(y.grad.cpu().numpy(), gy64.numpy(), rtol=0, atol=2e-4 * gscale + 1e-12)
+
+
+@pytest.mark.parametrize("s,ub,k,h,w,p,patch", [(3, 2, 6, 24, 20, 1, 1024), (2, 2, 5, 40, 40, 2, 16)])
+def test_local_mi_heads_equals_per_head_calls(s, ub, k, h, w, p, patch):
+    """The one-node multi-head path (gradient written into one [S,2UB,K,H,W] buffer) is the per-sub-head loop of
+    ref semi_seg/epocher.py:264-272, bit for bit (same kernels, same operands)."""
+    from contrastyou.losses.iic_loss import IIDSegmentationSmallPathLoss
+    crit = IIDSegmentationSmallPathLoss(padding=p, patch_size=patch)
+    base = T(synth.probs(f"heads_s{s}_ub{ub}_k{k}_h{h}_w{w}", (s * 2 * ub, k, h, w))).view(s, 2 * ub, k, h, w).to(DEV)
+    a = base.clone().requires_grad_(True)
+    fused = crit.forward_heads(a, ub)
+    (fused * torch.arange(1, s + 1, device=DEV)).sum().backward()
+    b = base.clone().requires_grad_(True)
+    loop = torch.stack([crit(q[:ub], q[ub:]) for q in b])
+    (loop * torch.arange(1, s + 1, device=DEV)).sum().backward()
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), loop.detach().cpu().numpy(), rtol=1e-6, atol=1e-8)
+    np.testing.assert_array_equal(a.grad.cpu().numpy(), b.grad.cpu().numpy())
+
+
+def test_simplex_checks_immediate_and_deferred():
+    """ref iic_loss.py:28-29 asserts simplex inline; here the same AssertionError is raised inline outside a
+    ``deferred`` block and at the block owner's fetch inside one (semi_seg/epocher.py _Pending)."""
+    from contrastyou.losses.iic_loss import IIDSegmentationLoss, simplex
+    from miseg_amd import checks
+    from semi_seg.epocher import _Pending
+    good = T(synth.probs("simplex/good", (2, 5, 9, 7))).to(DEV)
+    bad = good.clone()
+    bad[1, :, 4, 3] *= 1.01
+    assert simplex(good) and not simplex(bad)
+    assert int(checks.simplex_violations(bad, 1)) == 1
+    assert int(checks.simplex_violations(good.permute(0, 2, 3, 1).contiguous(), 3)) == 0
+    nan = good.clone()
+    nan[0, 2, 0, 0] = float("nan")
+    assert int(checks.simplex_violations(nan, 1)) == 1
+    crit = IIDSegmentationLoss(padding=1)
+    with pytest.raises(AssertionError):
+        crit(bad.requires_grad_(True), good.clone().requires_grad_(True))
+    pend = _Pending()
+    with checks.deferred(pend.checks):
+        loss = crit(bad, good.clone().requires_grad_(True))   # no exception yet
+        pend.put("loss", loss)
+    with pytest.raises(AssertionError):
+        pend.fetch()
+    assert pend.fetch() == {}   # flags are consumed
