@@ -112,48 +112,219 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
                 const int row = wv * 4 + m / MTR + ky, col = (m % MTR) * 16 + l15 + kx;
                 typename MM::Frag af = MM::load(Is + (row * IW + col) * CKP, kq);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) MM::mma_chunk(af, bf[t], acc[m][t]);
+                for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);   // D^T: rows = channels, cols = pixels
             }
         }
     }
-    // ---- epilogue: D[row = pixel kq*4+r][col = co l15]
-    float s1[NT], s2[NT];
+    // ---- epilogue: D^T[row = channel t*16 + kq*4 + r][col = pixel l15]: a lane owns 4 consecutive channels of one pixel, so
+    // the 16 lanes x 4 kq of a wave store whole NHWC pixel vectors (8-byte pieces, contiguous across kq)
+    float s1[NT][4], s2[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
-        const int h = h0 + wv * 4 + m / MTR;
+        const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+        const bool ok = h < H && w < W;
+        T* op = out + (((size_t)n * H + h) * W + w) * Cout;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int w = w0 + (m % MTR) * 16 + kq * 4 + r;
-            const bool ok = h < H && w < W;
+        for (int t = 0; t < NT; ++t) {
+            const int co = co0 + t * 16 + kq * 4;
+            if (ok && co + 3 < Cout) {
+                T pk[4];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int co = co0 + t * 16 + l15;
-                const float v = acc[m][t][r];
-                if (ok && co < Cout) {
-                    out[(((size_t)n * H + h) * W + w) * Cout + co] = from_f32<T>(v);
-                    s1[t] += v;
-                    s2[t] += v * v;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[m][t][r];
+                    pk[r] = from_f32<T>(v);
+                    s1[t][r] += v;
+                    s2[t][r] += v * v;
                 }
+                if (sizeof(T) == 2) *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                else *reinterpret_cast<uint4*>(op + co) = *reinterpret_cast<const uint4*>(pk);
+            } else if (ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < Cout) {
+                        const float v = acc[m][t][r];
+                        op[co + r] = from_f32<T>(v);
+                        s1[t][r] += v;
+                        s2[t][r] += v * v;
+                    }
             }
         }
     }
     if (stats) {
         __shared__ float sred[4][2][COT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float a = s1[t], b = s2[t];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (kq == 0) { sred[wv][0][t * 16 + l15] = a; sred[wv][1][t * 16 + l15] = b; }
-        }
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[t][r], b = s2[t][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    a += __shfl_xor(a, off, 64);
+                    b += __shfl_xor(b, off, 64);
+                }
+                if (l15 == 0) { sred[wv][0][t * 16 + kq * 4 + r] = a; sred[wv][1][t * 16 + kq * 4 + r] = b; }
+            }
         __syncthreads();
         if (tid < COT && co0 + tid < Cout) {
             float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
             float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
             stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
             stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
+        }
+    }
+}
+
+// Streaming variant for the HBM-bound layers (Cin <= 32, bf16): persistent blocks walk tiles; the next tile's haloed input
+// (NVEC 16-byte channel vectors per pixel) is fetched into registers while the current tile is on the matrix cores, and the
+// weight chunk is staged once per block.  Same arithmetic, tile shape, output and stats-part layout as conv3x3_kernel.
+// Logical block id is XCD-major (hardware deals consecutive workgroup ids round-robin to the 8 XCDs), so the tiles one
+// XCD works on in a sweep are contiguous and their halos hit that XCD's L2.
+template <int COT, int TW, int NVEC>
+__global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ wpk, int Cout,
+                                                               bf16* __restrict__ out, float* __restrict__ stats, int ntiles) {
+    typedef bf16 T;
+    typedef Mma<T> MM;
+    constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
+    constexpr int IW = TW + 2, IH = TH + 2, NSLOT = IH * IW * NVEC, NPF = (NSLOT + kCT - 1) / kCT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][CKP]
+    T* Ws = Is + IH * IW * CKP;                            // [9][COT][CKP]
+    const int Cin = src.C0 + src.C1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int tilesC = (W + TW - 1) / TW, tilesR = (H + TH - 1) / TH;
+    const int co0 = blockIdx.y * COT;
+    const int G = gridDim.x;
+    const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+
+    // channels [Cin, CK) of the tile stay zero for the whole kernel; the weight chunk is loaded once
+    for (int idx = tid; idx < IH * IW * (CK / VEC); idx += kCT) {
+        const int v = idx % (CK / VEC), px = idx / (CK / VEC);
+        if (v >= NVEC) zero_vec<T>(Is + px * CKP + v * VEC);
+    }
+    for (int idx = tid; idx < 9 * COT * (CK / VEC); idx += kCT) {
+        const int v = idx % (CK / VEC), co = (idx / (CK / VEC)) % COT, tap = idx / ((CK / VEC) * COT);
+        const int c = v * VEC;
+        T* dst = Ws + (tap * COT + co) * CKP + v * VEC;
+        if (co0 + co >= Cout || c >= Cin) { zero_vec<T>(dst); continue; }
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
+    }
+
+    uint4 pf[NPF];
+    auto fetch = [&](int tile) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int h0 = tr * TH, w0 = tc * TW;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int idx = tid + kCT * j;
+            const int v = idx % NVEC, px = idx / NVEC, ix = px % IW, iy = px / IW;
+            const int h = h0 - 1 + iy, w = w0 - 1 + ix, c = v * VEC;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NSLOT && h >= 0 && h < H && w >= 0 && w < W) {
+                const T* sp;
+                if (c < src.C0) {
+                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                    sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
+                } else {
+                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                    sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
+                }
+                val = *reinterpret_cast<const uint4*>(sp);
+            }
+            pf[j] = val;
+        }
+    };
+    if (lb < ntiles) fetch(lb);
+    for (int tile = lb; tile < ntiles; tile += G) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int h0 = tr * TH, w0 = tc * TW;
+        __syncthreads();                       // previous tile's MFMAs are done with Is
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int idx = tid + kCT * j;
+            if (idx < NSLOT) *reinterpret_cast<uint4*>(Is + (idx / NVEC) * CKP + (idx % NVEC) * VEC) = pf[j];
+        }
+        __syncthreads();
+        if (tile + G < ntiles) fetch(tile + G);
+
+        f32x4 acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            typename MM::Frag bf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[t] = MM::load(Ws + (tap * COT + t * 16 + l15) * CKP, kq);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int row = wv * 4 + m / MTR + ky, col = (m % MTR) * 16 + l15 + kx;
+                typename MM::Frag af = MM::load(Is + (row * IW + col) * CKP, kq);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);
+            }
+        }
+        float s1[NT][4], s2[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+            const bool ok = h < H && w < W;
+            T* op = out + (((size_t)n * H + h) * W + w) * Cout;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co0 + t * 16 + kq * 4;
+                if (ok && co + 3 < Cout) {
+                    T pk[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[m][t][r];
+                        pk[r] = from_f32<T>(v);
+                        s1[t][r] += v;
+                        s2[t][r] += v * v;
+                    }
+                    *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                } else if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < Cout) {
+                            const float v = acc[m][t][r];
+                            op[co + r] = from_f32<T>(v);
+                            s1[t][r] += v;
+                            s2[t][r] += v * v;
+                        }
+                }
+            }
+        }
+        if (stats) {
+            __shared__ float sred[4][2][COT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = s1[t][r], b = s2[t][r];
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        a += __shfl_xor(a, off, 64);
+                        b += __shfl_xor(b, off, 64);
+                    }
+                    if (l15 == 0) { sred[wv][0][t * 16 + kq * 4 + r] = a; sred[wv][1][t * 16 + kq * 4 + r] = b; }
+                }
+            __syncthreads();
+            if (tid < COT && co0 + tid < Cout) {
+                const float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
+                const float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+                stats[((size_t)tile * 2 + 0) * Cout + co0 + tid] = a;
+                stats[((size_t)tile * 2 + 1) * Cout + co0 + tid] = b;
+            }
         }
     }
 }
@@ -486,7 +657,23 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
         hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
                            (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats);                                       \
     }
-    if (dt == MISEG_BF16) {
+    if (dt == MISEG_BF16 && C0 + C1 <= CK && tw == 32 && gx >= 512 && !getenv("MISEG_NO_STREAM")) {
+        // HBM-bound shapes: persistent streaming kernel, 2 blocks per CU
+#define SLAUNCH(COT, NV)                                                                                                   \
+    {                                                                                                                     \
+        size_t lb = ((size_t)(TH + 2) * (32 + 2) + 9 * COT) * Mma<bf16>::CKP * sizeof(bf16);                               \
+        const unsigned g = (unsigned)std::min<int64_t>(gx, 512);                                                           \
+        hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
+                           (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx);                           \
+    }
+#define SLAUNCH_NV(COT) { switch ((C0 + C1) / 8) { case 1: SLAUNCH(COT, 1) break; case 2: SLAUNCH(COT, 2) break; case 3: SLAUNCH(COT, 3) break; default: SLAUNCH(COT, 4) break; } }
+        if (Cout <= 16) SLAUNCH_NV(16)
+        else if (Cout <= 32) SLAUNCH_NV(32)
+        else SLAUNCH_NV(64)
+#undef SLAUNCH_NV
+#undef SLAUNCH
+    } else if (dt == MISEG_BF16) {
         if (Cout <= 16) { if (tw == 32) LAUNCH(bf16, 16, 32) else LAUNCH(bf16, 16, 16) }
         else if (Cout <= 32) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
         else { if (tw == 32) LAUNCH(bf16, 64, 32) else LAUNCH(bf16, 64, 16) }

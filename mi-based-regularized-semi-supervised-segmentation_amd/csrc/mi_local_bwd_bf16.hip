@@ -3,13 +3,16 @@
 // Same transposed GEMM as local_bwd2_kernel (mi_local.hip), per output row h and direction:
 //   dA[(b,o), w] = sum_{kred=(a,c)} Gm[(b,o)][(a,c)] * S[c][h + s(a-p)][w]      M = T*K (140 -> 144), N = 64 px, Kred = T*K (140 -> 160)
 //   out[o][h][w'] = sum_b dA[(b,o), w' -+ (b-p)]                                 "col2im"
-// What is different on bf16 MFMA (v_mfma_f32_16x16x32_bf16):
-//   * A (the gradient matrix Gm) is packed once per call into bf16 hi/lo k-step slices [dir][ks][plane][144][32] (row-swizzled),
-//     and streamed L2 -> registers -> LDS one 18 KB slice ahead of the MFMAs (it no longer fits LDS whole);
-//   * B needs 8 consecutive reduction elements (= 8 channel planes of one pixel) per lane while the tile is planar [c][row][w]:
-//     ds_read_b64_tr_b16 transposes 4 planes x 16 pixels on the fly, so the tile keeps its coalescing-friendly layout;
-//   * col2im is a gather: each wave parks 3 M-tiles of D at a time in LDS and every lane (= one output column) sums the rows it
-//     needs into K registers -- independent LDS reads instead of the read-modify-write chain of the fp32 kernel.
+// Block = 512 threads = 8 waves = 2 waves per SIMD, so one wave's LDS / col2im / global phases overlap its SIMD partner's
+// MFMAs.  Wave w: output row (w & 3) of the item's 4 rows, M half (w >> 2) -- the two halves of a row sit on the same SIMD.
+//   * A (the gradient matrix Gm) is packed once per call into bf16 hi/lo k-step slices [dir][ks][plane][144][32] (row-swizzled)
+//     and streamed L2 -> registers -> LDS one slice ahead of the MFMAs, as one continuous double-buffered pipeline across
+//     items (one __syncthreads per k-step);
+//   * B: the source tile stays planar [c][row][w] in LDS; ds_read_b64_tr_b16 transposes 4 planes x 16 pixels on the fly into
+//     the 8-consecutive-k lane layout.  Rows live in a 12-row ring (3 groups of 4): a block walks a segment of consecutive
+//     4-row items down one 58-column strip and fetches only the 4 new rows per item (registers, one item ahead);
+//   * col2im is a gather: a wave parks one M-tile of D at a time in LDS as [col][16 rows] and every lane (= one output
+//     column) reads 4 rows per ds_read_b128 at its shifted column; the two M halves are summed through LDS.
 // K and PAD are template parameters (K=20; PAD=3 and 1: the shipped taps); other shapes use the fp32 kernels.
 #include "mi_local.h"
 
@@ -21,18 +24,26 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct Bwd3Geom {
     int N, H, W, P, G, accumulate;
+    int L;        // items (4-row tiles) per segment
+    int ablate;   // profiling only (MISEG_ABLATE): 1 no src tile, 2 no MFMA, 4 no col2im, 8 no output write, 16 no G streaming
 };
 
 template <int K, int PAD>
 struct B3 {
     static constexpr int T = 2 * PAD + 1, MD = T * K, MT = (MD + 15) / 16, MP = MT * 16, KRED = T * K, KS = (KRED + 31) / 32;
-    static constexpr int RS = 4 + 2 * PAD, WT = 64, WB = WT - 2 * PAD, SW = 72;
-    static constexpr int MG = MT >= 9 ? 3 : 2, NG = (MT + MG - 1) / MG;
+    static constexpr int WT = 64, WB = WT - 2 * PAD, SW = 72, RING = 12;
+    static constexpr int MH = (MT + 1) / 2;   // M tiles of half 0; half 1 owns MT - MH
+    static constexpr int DL = 20;             // floats per column of the col2im staging tile (16 rows + 4 pad; >= K)
+    static_assert(PAD <= 4 && K % 4 == 0 && K <= DL && (K * 4) % 8 == 0, "B3: unsupported shape");
 };
 
 __device__ __forceinline__ unsigned short bf16_hi(float v) { return f32_to_bf16_bits(v); }
 
-// gpack[p][dir][ks][pl][m][32]: value(m=(b,o), kred=(a,c)) = dir ? G[a,b,c,o] : G[a,b,o,c]; 16-byte slot s of row m stored at s ^ ((m>>2)&3)
+// workgroup barrier that publishes LDS writes but leaves global loads in flight (__syncthreads also drains vmcnt)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// gpack[p][dir][ks][pl][m][32]: value(m=(b,o), kred=(a,c)) = dir ? G[a,b,c,o] : G[a,b,o,c]; 16-byte slot s of row m stored at
+// s ^ (-(m>>2) & 3): with ds_read_b128's lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},.. the 16 lanes of a group then hit 64 distinct banks
 template <int K, int PAD, int NP>
 __global__ void pack_g_bf16_kernel(const float* __restrict__ grad_raw, int P, unsigned short* __restrict__ gpack) {
     typedef B3<K, PAD> C;
@@ -48,222 +59,290 @@ __global__ void pack_g_bf16_kernel(const float* __restrict__ grad_raw, int P, un
             v = dir ? G[c * K + o] : G[o * K + c];
         }
         const unsigned short hi = bf16_hi(v);
-        const size_t base = ((((size_t)(p * 2 + dir) * C::KS + ks) * NP) * C::MP + m) * 32 + 8 * ((kk >> 3) ^ ((m >> 2) & 3)) + (kk & 7);
+        const size_t base = ((((size_t)(p * 2 + dir) * C::KS + ks) * NP) * C::MP + m) * 32 + 8 * ((kk >> 3) ^ ((0 - (m >> 2)) & 3)) + (kk & 7);
         gpack[base] = hi;
         if (NP == 2) gpack[base + (size_t)C::MP * 32] = bf16_hi(v - bf16_bits_to_f32(hi));
     }
 }
 
 template <int K, int PAD, int NTERMS>
-__global__ __launch_bounds__(256, 1) void local_bwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ y, Bwd3Geom g,
+__global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ y, Bwd3Geom g,
                                                                 const int32_t* __restrict__ win,
                                                                 const unsigned short* __restrict__ gpack,
                                                                 const float* __restrict__ scale, float* __restrict__ gx,
                                                                 float* __restrict__ gy) {
     typedef B3<K, PAD> C;
     constexpr int NP = NTERMS == 1 ? 1 : 2, NT = 4;
-    constexpr int T = C::T, MT = C::MT, MP = C::MP, KS = C::KS, RS = C::RS, WT = C::WT, SW = C::SW, MG = C::MG, NG = C::NG;
+    constexpr int MT = C::MT, MP = C::MP, MH = C::MH, KS = C::KS, WT = C::WT, SW = C::SW, RING = C::RING, DL = C::DL;
     constexpr int SLICE = NP * MP * 32;                  // bf16 elements per k-step slice
-    constexpr int SPLANE = K * RS * SW, DROW = 65;
+    constexpr int SPLANE = K * RING * SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned short* Gsl = reinterpret_cast<unsigned short*>(ldsb);               // [2][NP][MP][32]
-    unsigned short* Ss = Gsl + 2 * SLICE;                                        // [NP][K][RS][SW]
-    float* Dst = reinterpret_cast<float*>(Ss + NP * SPLANE);                     // [4 waves][MG*16][DROW]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    float* Dw = Dst + (size_t)wv * MG * 16 * DROW;
+    unsigned short* Ss = Gsl + 2 * SLICE;                                        // [NP][K][RING][SW]
+    float* Dst = reinterpret_cast<float*>(Ss + NP * SPLANE);                     // [8 waves][64 cols][DL]
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r4 = wvu & 3, half = wvu >> 2;
+    float* Dw = Dst + (size_t)wvu * WT * DL;
+    const float* Dpartner = Dst + (size_t)(wvu + 4) * WT * DL;                   // half 1 of the same row (read by half 0 only)
     const size_t plane = (size_t)g.H * g.W;
 
+    // ---- segments: (dir, window p, sample n, column strip ct, run of <= L consecutive 4-row items)
     int64_t total = 0;
     for (int p = 0; p < g.P; ++p) {
-        int tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4, tc = (win[p * 4 + 3] - win[p * 4 + 2] + C::WB - 1) / C::WB;
-        total += (int64_t)g.N * tr * tc;
+        const int tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4, tc = (win[p * 4 + 3] - win[p * 4 + 2] + C::WB - 1) / C::WB;
+        total += (int64_t)g.N * tc * ((tr + g.L - 1) / g.L);
     }
-    struct Item { int dir, p, n, row0, col0, h0, h1, w0, w1; };
-    auto decode = [&](int64_t it, Item& o) {
-        o.dir = it >= total;
-        int64_t rem = it - (o.dir ? total : 0);
-        int p = 0, tr = 0, tc = 0;
+    struct Seg { int dir, p, n, col0, h0, h1, w0, w1, rt0, rt1; };
+    auto decode = [&](int64_t sid, Seg& o) {
+        o.dir = sid >= total;
+        int64_t rem = sid - (o.dir ? total : 0);
+        int p = 0, tr = 0, tc = 0, ns = 0;
         for (; p < g.P; ++p) {
             tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4;
             tc = (win[p * 4 + 3] - win[p * 4 + 2] + C::WB - 1) / C::WB;
-            int64_t cnt = (int64_t)g.N * tr * tc;
+            ns = (tr + g.L - 1) / g.L;
+            const int64_t cnt = (int64_t)g.N * tc * ns;
             if (rem < cnt) break;
             rem -= cnt;
         }
         o.p = p;
         o.h0 = win[p * 4 + 0]; o.h1 = win[p * 4 + 1]; o.w0 = win[p * 4 + 2]; o.w1 = win[p * 4 + 3];
-        const int ct = rem % tc, rt = (rem / tc) % tr;
-        o.n = rem / ((int64_t)tc * tr);
-        o.row0 = o.h0 + rt * 4; o.col0 = o.w0 + ct * C::WB;
+        const int sg = rem % ns, ct = (rem / ns) % tc;
+        o.n = rem / ((int64_t)ns * tc);
+        o.col0 = o.w0 + ct * C::WB;
+        o.rt0 = sg * g.L;
+        o.rt1 = min(tr, o.rt0 + g.L);
     };
-    // src tile prefetch (fp32 values in registers, split into bf16 planes at commit): (ch,row) pairs pr = wv + 4*bi
-    constexpr int PFN = (K * RS + 3) / 4;
-    float pf[PFN];
+
+    // ---- source rows: group j = rows h0+4j .. h0+4j+3 of all K planes; wave w owns (ch,row) pairs pr = w + 8*i; ring slot (j+1) % 3
+    constexpr int PFN = (K * 4) / 8;
     const unsigned tbytes = (unsigned)((size_t)g.N * K * plane * 4);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)tbytes, 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
-    auto prefetch = [&](const Item& o) {
+    auto fetch_group = [&](const Seg& o, int j, float* dst) {
         const int col = o.col0 - PAD + lane;
         const unsigned vo = (col >= o.w0 && col < o.w1) ? (unsigned)col * 4u : OOB;
 #pragma unroll
-        for (int bi = 0; bi < PFN; ++bi) {
-            const int pr = wvu + 4 * bi;
-            const int ch = pr / RS, r = pr - ch * RS, row = o.row0 - PAD + r;
-            const bool ok = pr < K * RS && row >= o.h0 && row < o.h1;
+        for (int i = 0; i < PFN; ++i) {
+            const int pr = wvu + 8 * i, ch = pr >> 2, r = pr & 3, row = o.h0 + 4 * j + r;
+            const bool ok = row >= o.h0 && row < o.h1;
             const unsigned so = ok ? (unsigned)((((size_t)o.n * K + ch) * plane + (size_t)row * g.W) * 4) : OOB;
-            pf[bi] = __uint_as_float(o.dir ? __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)(so + vo), 0, 0)
+            dst[i] = __uint_as_float(o.dir ? __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)(so + vo), 0, 0)
                                            : __builtin_amdgcn_raw_buffer_load_b32(rsy, (int)(so + vo), 0, 0));
         }
     };
-    auto commit = [&]() {
+    auto commit_group = [&](int slot, const float* src) {
 #pragma unroll
-        for (int bi = 0; bi < PFN; ++bi) {
-            const int pr = wv + 4 * bi;
-            if (pr < K * RS) {
-                const int ch = pr / RS, r = pr - ch * RS;
-                unsigned short* d = Ss + (ch * RS + r) * SW + lane;
-                const unsigned short hi = bf16_hi(pf[bi]);
-                d[0] = hi;
-                if (NP == 2) d[SPLANE] = bf16_hi(pf[bi] - bf16_bits_to_f32(hi));
-            }
+        for (int i = 0; i < PFN; ++i) {
+            const int pr = wvu + 8 * i, ch = pr >> 2, r = pr & 3;
+            unsigned short* d = Ss + (ch * RING + slot * 4 + r) * SW + lane;
+            const unsigned short hi = bf16_hi(src[i]);
+            d[0] = hi;
+            if (NP == 2) d[SPLANE] = bf16_hi(src[i] - bf16_bits_to_f32(hi));
         }
     };
-    // G slice streaming: SLICE*2 bytes = SLICE/8 uint4 per slice, <= 5 per thread
-    constexpr int GQ = (SLICE / 8 + 255) / 256;
+    // ---- G slice streaming: SLICE/8 uint4 per slice
+    constexpr int GQ = (SLICE / 8 + 511) / 512;
     u32x4 gq[GQ];
     auto gload = [&](const unsigned short* slice) {
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + 512 * i;
             if (idx < SLICE / 8) gq[i] = *reinterpret_cast<const u32x4*>(slice + (size_t)idx * 8);
         }
     };
     auto gstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + 512 * i;
             if (idx < SLICE / 8) *reinterpret_cast<u32x4*>(Gsl + (size_t)buf * SLICE + (size_t)idx * 8) = gq[i];
         }
     };
+    auto slices_of = [&](const Seg& o) { return gpack + (size_t)(o.p * 2 + o.dir) * KS * SLICE; };
 
-    Item cur, nxt;
-    if ((int64_t)blockIdx.x < 2 * total) { decode(blockIdx.x, cur); prefetch(cur); }
-    for (int64_t it = blockIdx.x; it < 2 * total; it += g.G) {
-        const int dir = cur.dir, p = cur.p, n = cur.n, row0 = cur.row0, col0 = cur.col0, h1 = cur.h1, w1 = cur.w1;
-        float* out = dir ? gy : gx;
-        const int sgn = dir ? 1 : -1;
-        const unsigned short* gbase = gpack + (size_t)(p * 2 + dir) * KS * SLICE;
-        __syncthreads();                         // previous item done with Ss / Gsl / Dst
-        commit();
-        gload(gbase);
-        gstore(0);
-        __syncthreads();
-        const bool more = it + g.G < 2 * total;
-        if (more) { decode(it + g.G, nxt); prefetch(nxt); }
-
-        f32x4 acc[MT][NT];
+    // pending output of the previous item (kept in registers until the partner half's partial is visible)
+    float outp[K];
+    int prow = 0, pcol0 = 0, pn = 0, pdir = 0, ph1 = 0, pw1 = 0, pp = 0;
+    bool pending = false;
+    auto finish_output = [&]() {
+        if (!pending || half != 0) return;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) gload(gbase + (size_t)(ks + 1) * SLICE);
-            const unsigned short* Gb = Gsl + (size_t)(ks & 1) * SLICE;
-            // B fragments: kred block of 8 = two 4-blocks kb, kb+4; 4-block -> (a, c0..c0+3) never straddles a (K % 4 == 0)
-            bf16x8_t bfr[NP][NT];
-            {
-                const int qq = l15 >> 2, pp = l15 & 3;
-                int soff[2];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int kb = min(ks * 32 + 8 * q + 4 * hf, C::KRED - 4);
-                    const int a = kb / K, c0 = kb - a * K;
-                    soff[hf] = ((c0 + qq) * RS + (wv + PAD + sgn * (a - PAD))) * SW + 4 * pp;
-                }
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Ss + pl * SPLANE + soff[0] + 16 * nt));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Ss + pl * SPLANE + soff[1] + 16 * nt));
-                        const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        bfr[pl][nt] = __builtin_bit_cast(bf16x8_t, f);
-                    }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = mt * 16 + l15;
-                bf16x8_t af[NP];
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    af[pl] = *reinterpret_cast<const bf16x8_t*>(Gb + ((size_t)pl * MP + m) * 32 + 8 * (q ^ ((m >> 2) & 3)));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (NTERMS == 3) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1], bfr[0][nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[NP - 1][nt], acc[mt][nt], 0, 0, 0);
-                    }
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[0][nt], acc[mt][nt], 0, 0, 0);
-                }
-            }
-            if (ks + 1 < KS) gstore((ks + 1) & 1);
-            __syncthreads();
+        for (int o4 = 0; o4 < K; o4 += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Dpartner + lane * DL + o4);
+            outp[o4] += v[0]; outp[o4 + 1] += v[1]; outp[o4 + 2] += v[2]; outp[o4 + 3] += v[3];
         }
-        // ---- col2im gather: lane = output tile column wc; out[o] += D[(b,o)][wc - shift(b)], shift = -sgn*(b-PAD)
-        float outv[K];
-#pragma unroll
-        for (int o = 0; o < K; ++o) outv[o] = 0.f;
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-#pragma unroll
-            for (int ml = 0; ml < MG; ++ml) {
-                const int mt = gi * MG + ml;
-                if (mt < MT) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Dw[(ml * 16 + q * 4 + r) * DROW + nt * 16 + l15] = acc[mt][nt][r];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-#pragma unroll
-            for (int rr = 0; rr < MG * 16; ++rr) {
-                const int m = gi * MG * 16 + rr;          // compile-time after unrolling
-                if (m < C::MD) {
-                    const int b = m / K, o = m % K;
-                    const int src_col = lane + sgn * (b - PAD);   // wc = w + shift  =>  w = wc - shift = wc + sgn*(b-PAD)
-                    const float v = (src_col >= 0 && src_col < WT) ? Dw[rr * DROW + src_col] : 0.f;
-                    outv[o] += v;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-        }
-        const int row = row0 + wv, col = col0 + lane - PAD;
-        if (row < h1 && lane >= PAD && lane < PAD + C::WB && col < w1) {
-            const float sc = scale[p];
-            float* op = out + (size_t)n * K * plane + (size_t)row * g.W + col;
+        const int col = pcol0 + lane - PAD;
+        if (prow < ph1 && lane >= PAD && lane < PAD + C::WB && col < pw1 && !((g.ablate & 8) && outp[0] != 12345.f)) {
+            const float sc = scale[pp];
+            float* op = (pdir ? gy : gx) + (size_t)pn * K * plane + (size_t)prow * g.W + col;
             if (g.accumulate) {
+                float old[K];
 #pragma unroll
-                for (int o = 0; o < K; ++o) op[(size_t)o * plane] += sc * outv[o];
+                for (int o = 0; o < K; ++o) old[o] = op[(size_t)o * plane];
+#pragma unroll
+                for (int o = 0; o < K; ++o) op[(size_t)o * plane] = old[o] + sc * outp[o];
             } else {
 #pragma unroll
-                for (int o = 0; o < K; ++o) op[(size_t)o * plane] = sc * outv[o];
+                for (int o = 0; o < K; ++o) op[(size_t)o * plane] = sc * outp[o];
             }
         }
-        cur = nxt;
+    };
+
+    const int64_t nseg = 2 * total;
+    Seg sg, sgn_;
+    int par = 0;   // G buffer holding the slice of the upcoming k-step
+    if ((int64_t)blockIdx.x < nseg) {
+        decode(blockIdx.x, sg);
+        gload(slices_of(sg));
+        gstore(0);
     }
+#pragma unroll 1
+    for (int64_t sid = blockIdx.x; sid < nseg; sid += g.G) {
+        const bool more_seg = sid + g.G < nseg;
+        if (more_seg) decode(sid + g.G, sgn_);
+        const int dir = sg.dir, sgn = dir ? 1 : -1;
+        const unsigned short* gbase = slices_of(sg);
+        __syncthreads();                         // previous item: MFMA phase done with Ss, partner partials written
+        finish_output();
+        pending = false;
+        if (!(g.ablate & 1)) {                   // warm the ring: groups rt0-1, rt0, rt0+1
+            float w3[3][PFN];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) fetch_group(sg, sg.rt0 - 1 + u, w3[u]);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) commit_group((sg.rt0 + u) % 3, w3[u]);
+        }
+        int base3 = sg.rt0 % 3;                  // ring slot of group rt-1
+        float pf[PFN];
+#pragma unroll 1
+        for (int rt = sg.rt0; rt < sg.rt1; ++rt) {
+            if (rt > sg.rt0) {
+                __syncthreads();
+                finish_output();
+                pending = false;
+                if (!(g.ablate & 1)) commit_group((base3 + 2) % 3, pf);       // group rt+1 replaces group rt-2
+            }
+            const bool more_rt = rt + 1 < sg.rt1;
+            if (more_rt && !(g.ablate & 1)) fetch_group(sg, rt + 2, pf);
+            auto body = [&](auto HC) {
+                constexpr int HALF = decltype(HC)::value;
+                constexpr int MT0 = HALF ? MH : 0, MTN = HALF ? MT - MH : MH;
+                f32x4 acc[MTN][NT];
+#pragma unroll
+                for (int ml = 0; ml < MTN; ++ml)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[ml][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int ks = 0; ks < KS; ++ks) {
+                    lds_barrier();               // slice `par` (and any ring commit) visible; everyone done with slice par^1
+                    const unsigned short* nxt = ks + 1 < KS ? gbase + (size_t)(ks + 1) * SLICE
+                                                : more_rt   ? gbase
+                                                : more_seg  ? slices_of(sgn_)
+                                                            : nullptr;
+                    const bool stream = nxt != nullptr && !((g.ablate & 16) && ks + 1 < KS);
+                    if (stream) gload(nxt);
+                    const unsigned short* Gb = Gsl + (size_t)par * SLICE;
+                    // B fragments: kred block of 8 = two 4-blocks kb, kb+4; 4-block -> (a, c0..c0+3) never straddles a (K % 4 == 0)
+                    bf16x8_t bfr[NP][NT];
+                    {
+                        const int qq = l15 >> 2, pq = l15 & 3;
+                        int soff[2];
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const int kb = min(ks * 32 + 8 * q + 4 * hf, C::KRED - 4);
+                            const int a = kb / K, c0 = kb - a * K;
+                            const int rr = r4 + sgn * (a - PAD);                 // source row relative to the item's first row: [-PAD, 3+PAD]
+                            int slot = base3 + 1 + ((rr + 4) >> 2) - 1;          // group rt + floor(rr/4) -> slot (group + 1) % 3
+                            slot = slot >= 3 ? slot - 3 : slot;
+                            soff[hf] = ((c0 + qq) * RING + slot * 4 + (rr & 3)) * SW + 4 * pq;
+                        }
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Ss + pl * SPLANE + soff[0] + 16 * nt));
+                                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Ss + pl * SPLANE + soff[1] + 16 * nt));
+                                const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                bfr[pl][nt] = __builtin_bit_cast(bf16x8_t, f);
+                            }
+                    }
+                    if (!(g.ablate & 2))
+#pragma unroll
+                        for (int ml = 0; ml < MTN; ++ml) {
+                            const int m = (MT0 + ml) * 16 + l15;
+                            bf16x8_t af[NP];
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl)
+                                af[pl] = *reinterpret_cast<const bf16x8_t*>(Gb + ((size_t)pl * MP + m) * 32 + 8 * (q ^ ((0 - (m >> 2)) & 3)));
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                if (NTERMS == 3) {
+                                    acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1], bfr[0][nt], acc[ml][nt], 0, 0, 0);
+                                    acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[NP - 1][nt], acc[ml][nt], 0, 0, 0);
+                                }
+                                acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[0][nt], acc[ml][nt], 0, 0, 0);
+                            }
+                        }
+                    if (stream) gstore(par ^ 1);
+                    if (nxt != nullptr) par ^= 1;
+                }
+                // ---- col2im gather: lane = output tile column wc; out[o] += D[(b,o)][wc + sgn*(b-PAD)]
+#pragma unroll
+                for (int o = 0; o < K; ++o) outp[o] = 0.f;
+                if (g.ablate & 4) {
+#pragma unroll
+                    for (int ml = 0; ml < MTN; ++ml)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) outp[(ml * NT + nt) % K] += acc[ml][nt][0] + acc[ml][nt][1] + acc[ml][nt][2] + acc[ml][nt][3];
+                } else {
+#pragma unroll
+                    for (int ml = 0; ml < MTN; ++ml) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(Dw + (nt * 16 + l15) * DL + 4 * q) = acc[ml][nt];
+                        __builtin_amdgcn_wave_barrier();
+                        __threadfence_block();
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int m = (MT0 + ml) * 16 + 4 * rq;           // compile-time after unrolling
+                            if (m < C::MD) {
+                                const int b = m / K, o = m % K;
+                                const int src_col = lane + sgn * (b - PAD);
+                                if (src_col >= 0 && src_col < WT) {
+                                    const f32x4 v = *reinterpret_cast<const f32x4*>(Dw + src_col * DL + 4 * rq);
+                                    outp[o] += v[0]; outp[o + 1] += v[1]; outp[o + 2] += v[2]; outp[o + 3] += v[3];
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        __threadfence_block();
+                    }
+                }
+                if (HALF == 1) {                 // park the partial sums for the row's half-0 wave: Dw[col][o]
+#pragma unroll
+                    for (int o4 = 0; o4 < K; o4 += 4)
+                        *reinterpret_cast<f32x4*>(Dw + lane * DL + o4) = f32x4{outp[o4], outp[o4 + 1], outp[o4 + 2], outp[o4 + 3]};
+                }
+            };
+            if (half == 0) body(std::integral_constant<int, 0>{});
+            else body(std::integral_constant<int, 1>{});
+            prow = sg.h0 + 4 * rt + r4; pcol0 = sg.col0; pn = sg.n; pdir = dir; ph1 = sg.h1; pw1 = sg.w1; pp = sg.p;
+            pending = true;
+            base3 = base3 == 2 ? 0 : base3 + 1;
+        }
+        sg = sgn_;
+    }
+    __syncthreads();
+    finish_output();
 }
 
 template <int K, int PAD>
 static size_t bwd3_lds(int nterms) {
     typedef B3<K, PAD> C;
     const int np = nterms == 1 ? 1 : 2;
-    return (size_t)2 * np * C::MP * 32 * 2 + (size_t)np * K * C::RS * C::SW * 2 + (size_t)4 * C::MG * 16 * 65 * 4;
+    return (size_t)2 * np * C::MP * 32 * 2 + (size_t)np * K * C::RING * C::SW * 2 + (size_t)8 * C::WT * C::DL * 4;
 }
 
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad) {
@@ -286,10 +365,10 @@ static int launch_bwd3(hipStream_t st, const float* x, const float* y, Bwd3Geom 
     const size_t lds = bwd3_lds<K, PAD>(nterms);
     if (nterms == 1) {
         hipFuncSetAttribute((const void*)local_bwd_bf16_kernel<K, PAD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_bwd_bf16_kernel<K, PAD, 1>), dim3(g.G), dim3(256), lds, st, x, y, g, win, gpack, scale, gx, gy);
+        hipLaunchKernelGGL((local_bwd_bf16_kernel<K, PAD, 1>), dim3(g.G), dim3(512), lds, st, x, y, g, win, gpack, scale, gx, gy);
     } else {
         hipFuncSetAttribute((const void*)local_bwd_bf16_kernel<K, PAD, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_bwd_bf16_kernel<K, PAD, 3>), dim3(g.G), dim3(256), lds, st, x, y, g, win, gpack, scale, gx, gy);
+        hipLaunchKernelGGL((local_bwd_bf16_kernel<K, PAD, 3>), dim3(g.G), dim3(512), lds, st, x, y, g, win, gpack, scale, gx, gy);
     }
     return 0;
 }
@@ -297,7 +376,17 @@ static int launch_bwd3(hipStream_t st, const float* x, const float* y, Bwd3Geom 
 int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
                           const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
                           void* ws, int nterms) {
-    Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate};
+    Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate, 8, 0};
+    { const char* ab = getenv("MISEG_ABLATE"); g.ablate = ab ? atoi(ab) : 0; }
+    if (P == 1) {   // one whole-image window (the shipped configuration): pick the segment length with the best block balance
+        const int wb = 64 - 2 * (int)pad, tr = ((int)H + 3) / 4, tc = ((int)W + wb - 1) / wb;
+        double best = 1e30;
+        for (int L = 4; L <= 64; L *= 2) {
+            const int64_t segs = 2 * N * tc * ((tr + L - 1) / L);
+            const double cost = (double)((segs + g.G - 1) / g.G) * (std::min(L, tr) + 1.0);   // +1: ring warm-up per segment
+            if (cost < best) { best = cost; g.L = L; }
+        }
+    }
     if (pad == 3) return launch_bwd3<20, 3>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
     return launch_bwd3<20, 1>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
 }

@@ -138,8 +138,11 @@ def test_unet_fp32_vs_golden(golden):
         worst[k] = float(np.linalg.norm(got - fp["sample"]) / (np.linalg.norm(fp["sample"]) + 1e-30))
     bad = {k: v for k, v in worst.items() if v > 5e-2}
     assert not bad, bad
-    tail = [worst[k] for k in worst if k.startswith(("Up_conv2", "DeConv"))]
-    assert max(tail) < 1e-3, tail   # the last layers see (almost) no flips: tight
+    # The last layers sit behind at most two ReLUs, so most of their gradients see no flip at all and must be tight.
+    # (Not all: this input has an Up_conv2 pre-activation of 3.9e-6 at scale 0.78 -- scratch analysis with the fp64
+    # oracle -- which lands on either side of zero depending on the fp32 summation order of the BN statistics.)
+    tail = sorted(worst[k] for k in worst if k.startswith(("Up_conv2", "DeConv")))
+    assert tail[len(tail) // 2] < 1e-4 and tail[0] < 1e-5, tail
     for k, v in net.state_dict().items():
         if "running" in k or "num_batches" in k:
             np.testing.assert_allclose(v.cpu().numpy(), g[f"train64/after/{k}"], rtol=1e-4, atol=1e-5)
