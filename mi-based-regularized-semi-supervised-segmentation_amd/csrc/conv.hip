@@ -471,22 +471,26 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
         for (int b = 0; b < 18; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-    for (int tile = split; tile < ntiles; tile += nsplit) {
+    // next tile's operands travel global -> registers while the current tile is on the matrix cores
+    constexpr int NG = NPX * 4 / kCT, NI = (NIPX * 4 + kCT - 1) / kCT;
+    uint4 pg[NG], pi[NI];
+    auto fetch = [&](int tile) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
         const int h0 = tr * WG_TH, w0 = tc * WG_TW;
-        __syncthreads();
-        for (int idx = tid; idx < NPX * 4; idx += kCT) {
-            const int v = idx & 3, px = idx >> 2, ix = px % WG_TW, iy = px / WG_TW;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, ix = px % WG_TW, iy = px / WG_TW;
             const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
             uint4 val = zero4;
             if (h < H && w < W && c < Cout) val = *reinterpret_cast<const uint4*>(gout + (((size_t)n * H + h) * W + w) * Cout + c);
-            *reinterpret_cast<uint4*>(Gs + ((v >> 1) * NPX + px) * 16 + (v & 1) * 8) = val;
+            pg[j] = val;
         }
-        for (int idx = tid; idx < NIPX * 4; idx += kCT) {
-            const int v = idx & 3, px = idx >> 2, ix = px % IW, iy = px / IW;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, ix = px % IW, iy = px / IW;
             const int h = h0 - 1 + iy, w = w0 - 1 + ix, cc = ci0 + v * 8;
             uint4 val = zero4;
-            if (h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
+            if (idx < NIPX * 4 && h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
                 const bf16* sp;
                 if (cc < src.C0) {
                     const int hs = H >> src.ups0, wsz = W >> src.ups0;
@@ -497,9 +501,24 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
                 }
                 val = *reinterpret_cast<const uint4*>(sp);
             }
-            *reinterpret_cast<uint4*>(Is + ((v >> 1) * NIPX + px) * 16 + (v & 1) * 8) = val;
+            pi[j] = val;
+        }
+    };
+    if (split < ntiles) fetch(split);
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2;
+            *reinterpret_cast<uint4*>(Gs + ((v >> 1) * NPX + px) * 16 + (v & 1) * 8) = pg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2;
+            if (idx < NIPX * 4) *reinterpret_cast<uint4*>(Is + ((v >> 1) * NIPX + px) * 16 + (v & 1) * 8) = pi[j];
         }
         __syncthreads();
+        if (tile + nsplit < ntiles) fetch(tile + nsplit);
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
             const int row = wv * 2 + rr;
