@@ -170,7 +170,7 @@ int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_
 int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w_oihw, int64_t Cout, int64_t Cin, int kind,
                                int64_t ci_begin, int64_t ci_count, void* packed);
 /* number of per-block (sum, sumsq) partial rows conv3x3_fwd writes: stats_partials = fp32[parts][2][Cout] */
-int64_t miseg_conv3x3_stats_parts(int64_t N, int64_t H, int64_t W);
+int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
 int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
                       int ups1, int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out,
                       float* stats_partials);

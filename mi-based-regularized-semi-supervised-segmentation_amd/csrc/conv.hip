@@ -180,19 +180,29 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
 
 // Streaming variant for the HBM-bound layers (Cin <= 32, bf16): persistent blocks walk tiles; the next tile's haloed input
 // (NVEC 16-byte channel vectors per pixel) is fetched into registers while the current tile is on the matrix cores, and the
-// weight chunk is staged once per block.  Same arithmetic, tile shape, output and stats-part layout as conv3x3_kernel.
+// weight chunk is staged once per block.  Same arithmetic, tile shape and output as conv3x3_kernel.  These layers are
+// instruction-issue bound, so everything tile-invariant is hoisted: per-slot byte offsets relative to a per-tile base (buffer
+// loads with a scalar base; out-of-image lanes get an out-of-range offset and read 0), a branch-free epilogue for interior
+// tiles, and BN statistics accumulated over all tiles of the block (one stats part per block: parts = gridDim.x).
 // Logical block id is XCD-major (hardware deals consecutive workgroup ids round-robin to the 8 XCDs), so the tiles one
 // XCD works on in a sweep are contiguous and their halos hit that XCD's L2.
-template <int COT, int TW, int NVEC>
+// DUAL (concat of two sources): slots are vector-major so that one load instruction reads one source.
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+template <int COT, int TW, int NVEC, bool DUAL>
 __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ wpk, int Cout,
                                                                bf16* __restrict__ out, float* __restrict__ stats, int ntiles) {
     typedef bf16 T;
     typedef Mma<T> MM;
     constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
-    constexpr int IW = TW + 2, IH = TH + 2, NSLOT = IH * IW * NVEC, NPF = (NSLOT + kCT - 1) / kCT;
+    // pixel stride of the input tile: 48 elements (24 dwords) makes the 16-lane groups of ds_read_b128 conflict-free
+    // (40 is 2-way); taken where the larger tile still leaves two blocks per CU
+    constexpr int IKP = COT == 16 ? 48 : CKP;
+    constexpr int IW = TW + 2, IH = TH + 2, NPIX = IH * IW;
+    constexpr int NPF = DUAL ? NVEC * ((NPIX + kCT - 1) / kCT) : (NPIX * NVEC + kCT - 1) / kCT;
+    constexpr unsigned OOB = 0xFFFFFF00u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][CKP]
-    T* Ws = Is + IH * IW * CKP;                            // [9][COT][CKP]
+    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][IKP]
+    T* Ws = Is + IH * IW * IKP;                            // [9][COT][CKP]
     const int Cin = src.C0 + src.C1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int tilesC = (W + TW - 1) / TW, tilesR = (H + TH - 1) / TH;
@@ -201,9 +211,9 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
     const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
 
     // channels [Cin, CK) of the tile stay zero for the whole kernel; the weight chunk is loaded once
-    for (int idx = tid; idx < IH * IW * (CK / VEC); idx += kCT) {
+    for (int idx = tid; idx < NPIX * (CK / VEC); idx += kCT) {
         const int v = idx % (CK / VEC), px = idx / (CK / VEC);
-        if (v >= NVEC) zero_vec<T>(Is + px * CKP + v * VEC);
+        if (v >= NVEC) zero_vec<T>(Is + px * IKP + v * VEC);
     }
     for (int idx = tid; idx < 9 * COT * (CK / VEC); idx += kCT) {
         const int v = idx % (CK / VEC), co = (idx / (CK / VEC)) % COT, tap = idx / ((CK / VEC) * COT);
@@ -213,41 +223,94 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
     }
 
-    uint4 pf[NPF];
+    // ---- tile-invariant slot tables: rel = byte offset from the tile base (pixel (h0-1, w0-1) of the source, after its x2
+    // upsampling shift), yx = iy | ix << 8 (0xFFFF for an unused slot), ldso = element offset into Is
+    const int hs0 = H >> src.ups0, ws0 = W >> src.ups0, hs1 = H >> src.ups1, ws1 = W >> src.ups1;
+    unsigned rel[NPF], yx[NPF];
+    unsigned short ldso[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        int v, px;
+        if (DUAL) { v = j % NVEC; px = tid + kCT * (j / NVEC); }
+        else { const int idx = tid + kCT * j; v = idx % NVEC; px = idx / NVEC; }
+        const int ix = px % IW, iy = px / IW, c = v * VEC;
+        const bool used = px < NPIX;
+        const bool from1 = c >= src.C0;
+        const int ups = from1 ? src.ups1 : src.ups0, wsz = from1 ? ws1 : ws0, Cs = from1 ? src.C1 : src.C0, cs = from1 ? c - src.C0 : c;
+        const int ry = ((iy - 1) >> ups) + 1, rx = ((ix - 1) >> ups) + 1;     // >= 0
+        rel[j] = (unsigned)(((ry * wsz + rx) * Cs + cs) * 2);
+        yx[j] = used ? (unsigned)(iy | (ix << 8)) : 0xFFFFu;
+        ldso[j] = (unsigned short)(used ? px * IKP + v * VEC : 0);
+    }
+
+    u32x4v pf[NPF];
     auto fetch = [&](int tile) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
         const int h0 = tr * TH, w0 = tc * TW;
+        const int ylo = h0 == 0 ? 1 : 0, yhi = min(IH, H - h0 + 1), xlo = w0 == 0 ? 1 : 0, xhi = min(IW, W - w0 + 1);
+        const long long b0 = ((((long long)n * hs0 + (h0 >> src.ups0) - 1) * ws0 + (w0 >> src.ups0) - 1) * src.C0) * 2;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)src.p0 + b0), 0, 0x7FFFFFFF, 0x00020000);
+        __amdgpu_buffer_rsrc_t r1 = r0;
+        if (DUAL) {
+            const long long b1 = ((((long long)n * hs1 + (h0 >> src.ups1) - 1) * ws1 + (w0 >> src.ups1) - 1) * src.C1) * 2;
+            r1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)src.p1 + b1), 0, 0x7FFFFFFF, 0x00020000);
+        }
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            const int idx = tid + kCT * j;
-            const int v = idx % NVEC, px = idx / NVEC, ix = px % IW, iy = px / IW;
-            const int h = h0 - 1 + iy, w = w0 - 1 + ix, c = v * VEC;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < NSLOT && h >= 0 && h < H && w >= 0 && w < W) {
-                const T* sp;
-                if (c < src.C0) {
-                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
-                    sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
-                } else {
-                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
-                    sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
+            const int iy = yx[j] & 0xFF, ix = yx[j] >> 8;
+            const bool ok = iy >= ylo && iy < yhi && ix >= xlo && ix < xhi;     // an unused slot has ix = 255
+            const unsigned off = ok ? rel[j] : OOB;
+            if (DUAL && (j % NVEC) * VEC >= src.C0) pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, (int)off, 0, 0);
+            else pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, (int)off, 0, 0);
+        }
+    };
+
+    // The epilogue of tile i is issued one iteration late (from packed registers), in front of the next loads: the
+    // s_waitcnt vmcnt(0) guarding the register->LDS commit then only sees memory operations one MFMA phase old.
+    uint2 pk[MTW][NT];
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
+    int ptile = -1;
+    auto store_prev = [&]() {
+        const int tc = ptile % tilesC, tr = (ptile / tilesC) % tilesR, n = ptile / (tilesC * tilesR);
+        const int h0 = tr * TH, w0 = tc * TW;
+        const bool full = h0 + TH <= H && w0 + TW <= W && co0 + COT <= Cout;
+        T* ob = out + (((size_t)n * H + h0 + wv * 4) * W + w0 + l15) * Cout + co0 + kq * 4;
+        if (full) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<uint2*>(ob + ((size_t)(m / MTR) * W + (m % MTR) * 16) * Cout + t * 16) = pk[m][t];
+        } else {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+                if (h < H && w < W) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const T* e = reinterpret_cast<const T*>(&pk[m][t]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + t * 16 + kq * 4 + r < Cout) ob[((size_t)(m / MTR) * W + (m % MTR) * 16) * Cout + t * 16 + r] = e[r];
+                    }
                 }
-                val = *reinterpret_cast<const uint4*>(sp);
             }
-            pf[j] = val;
         }
     };
     if (lb < ntiles) fetch(lb);
     for (int tile = lb; tile < ntiles; tile += G) {
-        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR;
         const int h0 = tr * TH, w0 = tc * TW;
         __syncthreads();                       // previous tile's MFMAs are done with Is
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int idx = tid + kCT * j;
-            if (idx < NSLOT) *reinterpret_cast<uint4*>(Is + (idx / NVEC) * CKP + (idx % NVEC) * VEC) = pf[j];
-        }
+        for (int j = 0; j < NPF; ++j)
+            if ((yx[j] & 0xFFFFu) != 0xFFFFu) *reinterpret_cast<u32x4v*>(Is + ldso[j]) = pf[j];
         __syncthreads();
+        if (ptile >= 0) store_prev();
         if (tile + G < ntiles) fetch(tile + G);
 
         f32x4 acc[MTW][NT];
@@ -255,7 +318,8 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+        const T* Ib = Is + ((wv * 4) * IW + l15) * IKP + 8 * kq;   // all 72 A-fragment reads are this base + an immediate
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             typename MM::Frag bf[NT];
@@ -263,68 +327,52 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             for (int t = 0; t < NT; ++t) bf[t] = MM::load(Ws + (tap * COT + t * 16 + l15) * CKP, kq);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const int row = wv * 4 + m / MTR + ky, col = (m % MTR) * 16 + l15 + kx;
-                typename MM::Frag af = MM::load(Is + (row * IW + col) * CKP, kq);
+                typename MM::Frag af = *reinterpret_cast<const typename MM::Frag*>(Ib + ((m / MTR + ky) * IW + (m % MTR) * 16 + kx) * IKP);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);
             }
         }
-        float s1[NT][4], s2[NT][4];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
+        // D^T[row = channel t*16 + kq*4 + r][col = pixel l15]: pack to bf16, accumulate the BN statistics of valid outputs
+        const bool full = h0 + TH <= H && w0 + TW <= W && co0 + COT <= Cout;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
-            const bool ok = h < H && w < W;
-            T* op = out + (((size_t)n * H + h) * W + w) * Cout;
+            const bool ok = full || (h < H && w < W);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int co = co0 + t * 16 + kq * 4;
-                if (ok && co + 3 < Cout) {
-                    T pk[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[m][t][r];
-                        pk[r] = from_f32<T>(v);
-                        s1[t][r] += v;
-                        s2[t][r] += v * v;
-                    }
-                    *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
-                } else if (ok) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co + r < Cout) {
-                            const float v = acc[m][t][r];
-                            op[co + r] = from_f32<T>(v);
-                            s1[t][r] += v;
-                            s2[t][r] += v * v;
-                        }
-                }
-            }
-        }
-        if (stats) {
-            __shared__ float sred[4][2][COT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
+                T e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float a = s1[t][r], b = s2[t][r];
-#pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) {
-                        a += __shfl_xor(a, off, 64);
-                        b += __shfl_xor(b, off, 64);
-                    }
-                    if (l15 == 0) { sred[wv][0][t * 16 + kq * 4 + r] = a; sred[wv][1][t * 16 + kq * 4 + r] = b; }
+                    const float v = acc[m][t][r];
+                    e[r] = from_f32<T>(v);
+                    const float vv = (full || (ok && co0 + t * 16 + kq * 4 + r < Cout)) ? v : 0.f;
+                    s1[t][r] += vv;
+                    s2[t][r] += vv * vv;
                 }
-            __syncthreads();
-            if (tid < COT && co0 + tid < Cout) {
-                const float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
-                const float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
-                stats[((size_t)tile * 2 + 0) * Cout + co0 + tid] = a;
-                stats[((size_t)tile * 2 + 1) * Cout + co0 + tid] = b;
+                pk[m][t] = *reinterpret_cast<const uint2*>(e);
             }
+        }
+        ptile = tile;
+    }
+    if (ptile >= 0) store_prev();
+    if (stats) {   // one part per block (zero for a block without tiles)
+        __shared__ float sred[4][2][COT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[t][r], b = s2[t][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    a += __shfl_xor(a, off, 64);
+                    b += __shfl_xor(b, off, 64);
+                }
+                if (l15 == 0) { sred[wv][0][t * 16 + kq * 4 + r] = a; sred[wv][1][t * 16 + kq * 4 + r] = b; }
+            }
+        __syncthreads();
+        if (tid < COT && co0 + tid < Cout) {
+            stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
+            stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
         }
     }
 }
@@ -651,7 +699,14 @@ extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, 
     return MISEG_OK;
 }
 
-extern "C" int64_t miseg_conv3x3_stats_parts(int64_t N, int64_t H, int64_t W) {
+// the persistent streaming kernel serves the HBM-bound bf16 shapes (one channel chunk, enough tiles to fill the chip)
+static bool conv_streams(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
+    return dt == MISEG_BF16 && Cin <= CK && tile_w(W) == 32 && N * cdiv(H, TH) * cdiv(W, 32) >= 512 && !getenv("MISEG_NO_STREAM");
+}
+static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) { return std::min<int64_t>(N * cdiv(H, TH) * cdiv(W, 32), 512); }
+
+extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
+    if (conv_streams(dt, Cin, N, H, W)) return stream_blocks(N, H, W);
     const int tw = tile_w(W);
     return N * cdiv(H, TH) * cdiv(W, tw);
 }
@@ -676,17 +731,20 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
         hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
                            (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats);                                       \
     }
-    if (dt == MISEG_BF16 && C0 + C1 <= CK && tw == 32 && gx >= 512 && !getenv("MISEG_NO_STREAM")) {
-        // HBM-bound shapes: persistent streaming kernel, 2 blocks per CU
-#define SLAUNCH(COT, NV)                                                                                                   \
+    if (conv_streams(dt, C0 + C1, N, H, W)) {
+#define SLAUNCH(COT, NV, DU)                                                                                               \
     {                                                                                                                     \
-        size_t lb = ((size_t)(TH + 2) * (32 + 2) + 9 * COT) * Mma<bf16>::CKP * sizeof(bf16);                               \
-        const unsigned g = (unsigned)std::min<int64_t>(gx, 512);                                                           \
-        hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-        hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
+        size_t lb = ((size_t)(TH + 2) * (32 + 2) * (COT == 16 ? 48 : Mma<bf16>::CKP) + 9 * COT * Mma<bf16>::CKP) * sizeof(bf16);      \
+        const unsigned g = (unsigned)stream_blocks(N, H, W);                                                               \
+        hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, DU>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
                            (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx);                           \
     }
-#define SLAUNCH_NV(COT) { switch ((C0 + C1) / 8) { case 1: SLAUNCH(COT, 1) break; case 2: SLAUNCH(COT, 2) break; case 3: SLAUNCH(COT, 3) break; default: SLAUNCH(COT, 4) break; } }
+#define SLAUNCH_NV(COT)                                                                                                    \
+    {                                                                                                                     \
+        if (C1 > 0) { switch ((C0 + C1) / 8) { case 2: SLAUNCH(COT, 2, true) break; case 3: SLAUNCH(COT, 3, true) break; default: SLAUNCH(COT, 4, true) break; } } \
+        else { switch (C0 / 8) { case 1: SLAUNCH(COT, 1, false) break; case 2: SLAUNCH(COT, 2, false) break; case 3: SLAUNCH(COT, 3, false) break; default: SLAUNCH(COT, 4, false) break; } } \
+    }
         if (Cout <= 16) SLAUNCH_NV(16)
         else if (Cout <= 32) SLAUNCH_NV(32)
         else SLAUNCH_NV(64)

@@ -63,7 +63,7 @@ class _ConvBNReLU(torch.autograd.Function):
         raw = empty_nhwc(n, cout, h, w, dtype, dev)
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         if training:
-            parts = query("miseg_conv3x3_stats_parts", n, h, w)
+            parts = query("miseg_conv3x3_stats_parts", _DT[dtype], c0 + c1, n, h, w)
             stats = torch.empty(parts * 2 * cout, dtype=torch.float32, device=dev)
         else:
             parts, stats = 0, None
