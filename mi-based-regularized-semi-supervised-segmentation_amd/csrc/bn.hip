@@ -115,58 +115,50 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ 
     }
 }
 
-// ---- backward pass 1: dz = (gy [+ routed gpool]) * (y > 0); writes dz into graw, per-block channel sums of
-//      dz and dz*xhat.  One thread = one 2x2 window x V channels (H, W even when gpool != NULL; any size otherwise
-//      via the 1x1 "window" path).
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ raw, const T* __restrict__ y, const T* __restrict__ gy,
-                                                                 const T* __restrict__ gpool, int N, int H, int W, int C,
-                                                                 const float* __restrict__ saved, T* __restrict__ graw,
-                                                                 float* __restrict__ parts) {
+// ---- backward.  dz = (gy [+ routed gpool]) * (y > 0) is never materialised and y is never read: both passes recompute
+//      y = T(relu(raw*scale+shift)) exactly as bn_relu_fwd_kernel stored it (same fp32 expression, same rounding to T), which
+//      gives the ReLU mask and, for the pooled layers, the first-max routing.  Pass 1 reads (raw, gy[, gpool]) and reduces
+//      sum(dz), sum(dz*xhat) per block; pass 2 re-reads them and writes graw = a*(dz - b - xhat*c).
+//      One thread = V channels of one pixel (POOL: of one 2x2 window; H, W even).
+template <typename T, bool POOL, typename F>
+__device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T* __restrict__ gy, const T* __restrict__ gpool, int N, int H,
+                                              int W, int C, const float* __restrict__ saved, int64_t first, int64_t step, int cv, F&& f) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
-    extern __shared__ float sacc[];  // [256][2*V] transposed reduce
     const int CV = C / V;
-    const float* mean = saved;
-    const float* invstd = saved + C;
-    // threads are assigned a fixed channel vector: stride over pixels with step (total threads / CV)
-    const int tpb = 256, lanesPerPix = CV;  // requires (gridDim.x*256) % CV == 0 (host guarantees CV | 256)
-    const int64_t gthreads = (int64_t)gridDim.x * tpb;
-    const int64_t gid = blockIdx.x * (int64_t)tpb + threadIdx.x;
-    const int cv = gid % lanesPerPix;
-    float a1[V], a2[V];
+    float sc[V], sh[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) a1[i] = a2[i] = 0.f;
+    for (int i = 0; i < V; ++i) { sc[i] = saved[2 * C + cv * V + i]; sh[i] = saved[3 * C + cv * V + i]; }
     if (!POOL) {
         const int64_t npix = (int64_t)N * H * W;
-        for (int64_t px = gid / lanesPerPix; px < npix; px += gthreads / lanesPerPix) {
+        for (int64_t px = first; px < npix; px += step) {
             const int64_t o = px * CV + cv;
-            float fy[V], fg[V], fr[V];
-            VT<T>::unpack(reinterpret_cast<const Raw*>(y)[o], fy);
-            VT<T>::unpack(reinterpret_cast<const Raw*>(gy)[o], fg);
+            float fr[V], fg[V], fy[V];
             VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[o], fr);
+            VT<T>::unpack(reinterpret_cast<const Raw*>(gy)[o], fg);
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                const float dz = fy[i] > 0.f ? fg[i] : 0.f;
-                fg[i] = dz;
-                a1[i] += dz;
-                a2[i] += dz * (fr[i] - mean[cv * V + i]) * invstd[cv * V + i];
-            }
-            reinterpret_cast<Raw*>(graw)[o] = VT<T>::pack(fg);
+            for (int i = 0; i < V; ++i) fy[i] = fmaxf(fr[i] * sc[i] + sh[i], 0.f);
+            VT<T>::unpack(VT<T>::pack(fy), fy);
+#pragma unroll
+            for (int i = 0; i < V; ++i) fg[i] = fy[i] > 0.f ? fg[i] : 0.f;
+            f(o, fr, fg);
         }
     } else {
         const int Hp = H / 2, Wp = W / 2;
         const int64_t nwin = (int64_t)N * Hp * Wp;
-        for (int64_t wi = gid / lanesPerPix; wi < nwin; wi += gthreads / lanesPerPix) {
+        for (int64_t wi = first; wi < nwin; wi += step) {
             const int wp = wi % Wp, hp = (wi / Wp) % Hp, n = wi / ((int64_t)Wp * Hp);
-            float gp[V], ys[4][V], best[V];
+            float gp[V], fr[4][V], ys[4][V], best[V];
             int arg[V];
             VT<T>::unpack(reinterpret_cast<const Raw*>(gpool)[wi * CV + cv], gp);
             int64_t offs[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 offs[q] = ((((int64_t)n * H + 2 * hp + (q >> 1)) * W + 2 * wp + (q & 1)) * CV + cv);
-                VT<T>::unpack(reinterpret_cast<const Raw*>(y)[offs[q]], ys[q]);
+                VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[offs[q]], fr[q]);
+#pragma unroll
+                for (int i = 0; i < V; ++i) ys[q][i] = fmaxf(fr[q][i] * sc[i] + sh[i], 0.f);
+                VT<T>::unpack(VT<T>::pack(ys[q]), ys[q]);
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -177,25 +169,43 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float fg[V], fr[V];
+                float fg[V];
                 if (gy) VT<T>::unpack(reinterpret_cast<const Raw*>(gy)[offs[q]], fg);
                 else {
 #pragma unroll
                     for (int i = 0; i < V; ++i) fg[i] = 0.f;
                 }
-                VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[offs[q]], fr);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    float g = fg[i] + (arg[i] == q ? gp[i] : 0.f);
-                    const float dz = ys[q][i] > 0.f ? g : 0.f;
-                    fg[i] = dz;
-                    a1[i] += dz;
-                    a2[i] += dz * (fr[i] - mean[cv * V + i]) * invstd[cv * V + i];
+                    const float g = fg[i] + (arg[i] == q ? gp[i] : 0.f);
+                    fg[i] = ys[q][i] > 0.f ? g : 0.f;
                 }
-                reinterpret_cast<Raw*>(graw)[offs[q]] = VT<T>::pack(fg);
+                f(offs[q], fr[q], fg);
             }
         }
     }
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ raw, const T* __restrict__ gy,
+                                                                 const T* __restrict__ gpool, int N, int H, int W, int C,
+                                                                 const float* __restrict__ saved, float* __restrict__ parts) {
+    constexpr int V = VT<T>::V;
+    extern __shared__ float sacc[];  // [256][2*V] transposed reduce
+    const int CV = C / V;
+    // threads keep a fixed channel vector and stride over pixels (CV | 256, so gid % CV is the same for every step)
+    const int64_t gthreads = (int64_t)gridDim.x * 256, gid = blockIdx.x * 256LL + threadIdx.x;
+    const int cv = gid % CV;
+    float mean[V], invstd[V], a1[V], a2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a1[i] = a2[i] = 0.f; mean[i] = saved[cv * V + i]; invstd[i] = saved[C + cv * V + i]; }
+    bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, [&](int64_t, const float* fr, const float* dz) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            a1[i] += dz[i];
+            a2[i] += dz[i] * (fr[i] - mean[i]) * invstd[i];
+        }
+    });
     // block reduce over threads sharing cv (256 % CV == 0): sacc[tid][2V]
 #pragma unroll
     for (int i = 0; i < V; ++i) { sacc[threadIdx.x * 2 * V + i] = a1[i]; sacc[threadIdx.x * 2 * V + V + i] = a2[i]; }
@@ -234,26 +244,31 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-// graw = a*(dz - b - xhat*c)
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ raw, int64_t nvec, int C, const float* __restrict__ saved,
+// graw = a*(dz - b - xhat*c), dz recomputed from (raw, gy[, gpool])
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ raw, const T* __restrict__ gy, const T* __restrict__ gpool,
+                                                           int N, int H, int W, int C, const float* __restrict__ saved,
                                                            const float* __restrict__ coeffs, T* __restrict__ graw) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
     const int CV = C / V;
-    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
-        const int cv = e % CV;
-        float fr[V], fd[V];
-        VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[e], fr);
-        VT<T>::unpack(reinterpret_cast<const Raw*>(graw)[e], fd);
+    const int64_t gthreads = (int64_t)gridDim.x * 256, gid = blockIdx.x * 256LL + threadIdx.x;
+    const int cv = gid % CV;
+    float mean[V], invstd[V], ca[V], cb[V], cc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = cv * V + i;
+        mean[i] = saved[c]; invstd[i] = saved[C + c]; ca[i] = coeffs[c]; cb[i] = coeffs[C + c]; cc[i] = coeffs[2 * C + c];
+    }
+    bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, [&](int64_t o, const float* fr, const float* dz) {
+        float fd[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const int c = cv * V + i;
-            const float xhat = (fr[i] - saved[c]) * saved[C + c];
-            fd[i] = coeffs[c] * (fd[i] - coeffs[C + c] - xhat * coeffs[2 * C + c]);
+            const float xhat = (fr[i] - mean[i]) * invstd[i];
+            fd[i] = ca[i] * (dz[i] - cb[i] - xhat * cc[i]);
         }
-        reinterpret_cast<Raw*>(graw)[e] = VT<T>::pack(fd);
-    }
+        reinterpret_cast<Raw*>(graw)[o] = VT<T>::pack(fd);
+    });
 }
 
 template <typename T>
@@ -369,7 +384,8 @@ extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_
 extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
                                  int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
                                  float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
-    MISEG_REQUIRE(raw && y && (gy || gpool) && gamma && saved && graw && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
+    (void)y;   // kept in the signature; the ReLU mask and pool routing are recomputed from raw (see bn_dz_foreach)
+    MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && graw && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     const int CV = (int)(C / V);
     MISEG_REQUIRE(C % V == 0 && 256 % CV == 0, "bn_relu_bwd: C/%d must divide 256", V);
@@ -381,7 +397,7 @@ extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const vo
     float* parts = (float*)ws;
     float* coeffs = parts + (size_t)nb * 2 * C;
     const size_t lb = (size_t)256 * 2 * V * 4;
-#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)y, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, (TT*)graw, parts)
+#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts)
     if (dt == MISEG_F32) { if (gpool) RED(float, true); else RED(float, false); }
     else if (dt == MISEG_BF16) { if (gpool) RED(bf16, true); else RED(bf16, false); }
     else return fail(MISEG_E_INVALID, "bn_relu_bwd: bad dtype");
@@ -389,9 +405,12 @@ extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const vo
     MISEG_LAUNCH_CHECK("bn_relu_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta);
     MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
-    const int64_t nvec = npix * CV;
-    if (dt == MISEG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const float*)raw, nvec, (int)C, saved, coeffs, (float*)graw);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_blocks(nvec)), dim3(256), 0, st, (const bf16*)raw, nvec, (int)C, saved, coeffs, (bf16*)graw);
+    // elementwise pass: many more blocks than the reduce (no partials to bound), same thread -> channel-vector mapping
+    const int na = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((gpool ? npix / 4 : npix) * CV, 256), 8192));
+#define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw)
+    if (dt == MISEG_F32) { if (gpool) APP(float, true); else APP(float, false); }
+    else { if (gpool) APP(bf16, true); else APP(bf16, false); }
+#undef APP
     MISEG_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return MISEG_OK;
 }
