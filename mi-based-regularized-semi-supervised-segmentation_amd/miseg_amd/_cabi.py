@@ -81,10 +81,14 @@ class KernelTimer:
     """Optional per-entry-point device timing with HIP events on the launching stream (bench.py roofline).
     ``work`` = algorithmic (flops, bytes) of the call, supplied by the caller of ``call``."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}  # name -> [ [start_event, end_event], flops, bytes ]
+        self.only = only   # None = every tagged call; else the set of tags to time (keeps host overhead off the rest)
 
     def wrap(self, name, work, fn):
+        if self.only is not None and name not in self.only:
+            fn()
+            return
         import torch
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

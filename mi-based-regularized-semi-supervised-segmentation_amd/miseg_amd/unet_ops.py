@@ -70,7 +70,7 @@ class _ConvBNReLU(torch.autograd.Function):
         es = x0.element_size()
         call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
              _ptr(stats), work=(18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout)),
-             tag="conv3x3_fwd")
+             tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
         if training:
             call("miseg_bn_finalize", _stream(), _ptr(stats), parts, cout, n * h * w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved))
@@ -106,7 +106,7 @@ class _ConvBNReLU(torch.autograd.Function):
             ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
             call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
                  _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
-                 tag="conv3x3_wgrad")
+                 tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
         grads = [None, None]
         for s, (cb, cs, ups, xs) in enumerate(((0, c0, ups0, x0), (c0, c1, ups1, x1))):
             if xs is None or not ctx.needs_input_grad[s]:
@@ -114,7 +114,7 @@ class _ConvBNReLU(torch.autograd.Function):
             packed = _pack(weight, dtype, 1, cb, cs)
             gfull = empty_nhwc(n, cs, h, w, dtype, dev)
             call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(graw), cout, 0, None, 0, 0, n, h, w, _ptr(packed), cs, _ptr(gfull), None,
-                 work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs + cout)), tag="conv3x3_dgrad")
+                 work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs + cout)), tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
             if ups:
                 glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
                 call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)
