@@ -92,10 +92,42 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 // Deterministic sum over `nparts` partial vectors: out[e] = sum_q parts[q*stride + map(e)].
 // 64 outputs x 4 split-groups per 256-thread block; each group sums q = g, g+4, ... serially, the 4 group
 // sums are added in fixed order -> bitwise reproducible, 4x the memory-level parallelism of one thread per output.
+// reduce_partials_block: outputs per block depend on the number of parts (host side: reduce_grid)
+constexpr int kWideReduceParts = 64;
+static inline unsigned reduce_grid(int64_t total, int64_t nparts) {
+    return (unsigned)((total + (nparts >= kWideReduceParts ? 15 : 63)) / (nparts >= kWideReduceParts ? 16 : 64));
+}
+
 template <typename MapFn>
 __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
                                                       float* __restrict__ out, MapFn map) {
-    __shared__ float rp_sm[4][64];
+    __shared__ float rp_sm[16][64];
+    if (nparts >= kWideReduceParts) {
+        // many parts, (usually) few outputs: 16 outputs x 16 part-groups per block, 4 independent chains per thread,
+        // then a fixed-order tree over the groups -- same result for any grid, ~16x the loads in flight of the narrow form
+        const int o = threadIdx.x & 15, grp = threadIdx.x >> 4, e = blockIdx.x * 16 + o;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (e < total) {
+            const float* p = parts + map(e);
+            int q = grp;
+            for (; q + 48 < nparts; q += 64) {
+                s0 += p[(size_t)q * stride];
+                s1 += p[(size_t)(q + 16) * stride];
+                s2 += p[(size_t)(q + 32) * stride];
+                s3 += p[(size_t)(q + 48) * stride];
+            }
+            for (; q < nparts; q += 16) s0 += p[(size_t)q * stride];
+        }
+        rp_sm[grp][o] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (grp == 0 && e < total) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += rp_sm[g][o];
+            out[e] = s;
+        }
+        return;
+    }
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s = 0.f;
     if (e < total) {

@@ -745,9 +745,10 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
         if (C1 > 0) { switch ((C0 + C1) / 8) { case 2: SLAUNCH(COT, 2, true) break; case 3: SLAUNCH(COT, 3, true) break; default: SLAUNCH(COT, 4, true) break; } } \
         else { switch (C0 / 8) { case 1: SLAUNCH(COT, 1, false) break; case 2: SLAUNCH(COT, 2, false) break; case 3: SLAUNCH(COT, 3, false) break; default: SLAUNCH(COT, 4, false) break; } } \
     }
+        // wider outputs run as 32-channel slices (grid.y): a 64-channel block would need 97 KB of LDS and the whole
+        // register file, i.e. one block per CU; re-reading the (narrow) input per slice is cheaper
         if (Cout <= 16) SLAUNCH_NV(16)
-        else if (Cout <= 32) SLAUNCH_NV(32)
-        else SLAUNCH_NV(64)
+        else SLAUNCH_NV(32)
 #undef SLAUNCH_NV
 #undef SLAUNCH
     } else if (dt == MISEG_BF16) {
@@ -796,7 +797,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
     } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
     MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     const int total = (int)(Cout * Cin * 9);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(total, ns)), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
     MISEG_LAUNCH_CHECK("wgrad_reduce_kernel");
     return MISEG_OK;
 }
@@ -847,7 +848,7 @@ extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const flo
     const int len = (int)(Cout * Cin + Cout);
     // gw [Cout*Cin] and gbias [Cout] are reduced into one contiguous scratch vector, then split
     float* red = (float*)ws + (size_t)nb * len;
-    hipLaunchKernelGGL(sum_parts2_kernel, dim3((len + 63) / 64), dim3(256), 0, st, (const float*)ws, nb, len, red);
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3(reduce_grid(len, nb)), dim3(256), 0, st, (const float*)ws, nb, len, red);
     MISEG_LAUNCH_CHECK("sum_parts2_kernel");
     hipMemcpyAsync(gw, red, (size_t)Cout * Cin * 4, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(gbias, red + Cout * Cin, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st);

@@ -599,7 +599,7 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
     }
     MISEG_LAUNCH_CHECK("joint_fwd_kernel");
     int64_t total = (int64_t)P * g.T * g.T * K * K;
-    hipLaunchKernelGGL(joint_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, (const float*)ws, g, cap, raw);
+    hipLaunchKernelGGL(joint_reduce_kernel, dim3(reduce_grid(total, g.G)), dim3(256), 0, st, (const float*)ws, g, cap, raw);
     MISEG_LAUNCH_CHECK("joint_reduce_kernel");
     return MISEG_OK;
 }
