@@ -87,7 +87,8 @@ class GradReducer:
         return hook
 
     def _launch(self, b: int) -> None:
-        _, _, start, end = self.buckets[b]
+        lo, hi, start, end = self.buckets[b]
+        self.flat.collect(lo, hi)   # gradients that autograd parked elsewhere (or that never arrived) -> flat slice
         view = self.flat.flat_grad[start:end]
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         self._handles[b] = dist.all_reduce(view, op=op, group=self.group, async_op=True)

@@ -17,16 +17,23 @@ import torch
 from torch import Tensor
 
 from . import unet_ops
+from .gradslot import grad_slot  # noqa: F401  (re-exported)
 
 
 class FlatBuffers:
-    """Owns the flat param / grad buffers of a list of parameters (all on one GPU, fp32)."""
+    """Owns the flat param / grad buffers of a list of parameters (all on one GPU, fp32).
+
+    Gradient protocol: ``zero_grad()`` drops every ``.grad`` (no fill kernel) and opens the slots; during backward our
+    conv / BN nodes write straight into their slots (``grad_slot``), every other gradient arrives wherever autograd put it;
+    ``collect()`` -- called by the optimiser step and by the data-parallel reducer before a bucket is reduced -- moves
+    stragglers into the flat buffer and zero-fills the slots of parameters that received no gradient."""
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
         self.flat_param: Optional[Tensor] = None
         self.flat_grad: Optional[Tensor] = None
         self.offsets: List[int] = []
+        self.slots: List[Tensor] = []
         self.total = 0
 
     def valid(self) -> bool:
@@ -34,8 +41,7 @@ class FlatBuffers:
             return False
         first, last = self.params[0], self.params[-1]
         base = self.flat_param.data_ptr()
-        return first.data_ptr() == base and last.data_ptr() == base + 4 * self.offsets[-1] and \
-            (last.grad is not None and last.grad.data_ptr() == self.flat_grad.data_ptr() + 4 * self.offsets[-1])
+        return first.data_ptr() == base and last.data_ptr() == base + 4 * self.offsets[-1]
 
     def build(self) -> None:
         dev = self.params[0].device  # any device: the reducer's bucketing is also exercised on CPU/gloo in the tests;
@@ -49,6 +55,7 @@ class FlatBuffers:
         self.total = off
         flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.slots = []
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = flat_p[o:o + p.numel()].view_as(p)
@@ -56,8 +63,11 @@ class FlatBuffers:
                 gview = flat_g[o:o + p.numel()].view_as(p)
                 if p.grad is not None:
                     gview.copy_(p.grad)
+                    p.grad = gview
                 p.data = view
-                p.grad = gview
+                p._miseg_grad_slot = gview
+                p._miseg_grad_claimed = True   # slots open at zero_grad()
+                self.slots.append(gview)
         self.flat_param, self.flat_grad = flat_p, flat_g
 
     def ensure(self) -> None:
@@ -66,10 +76,25 @@ class FlatBuffers:
 
     def zero_grad(self) -> None:
         self.ensure()
-        self.flat_grad.zero_()
-        for p, o in zip(self.params, self.offsets):  # re-attach views dropped by set_to_none-style code
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        for p in self.params:
+            p.grad = None
+            p._miseg_grad_claimed = False
+
+    def collect(self, lo: int = 0, hi: Optional[int] = None) -> None:
+        """Make ``flat_grad[offsets[lo]:offsets[hi])`` hold the gradients of params[lo:hi] (see class docstring)."""
+        self.ensure()
+        hi = len(self.params) if hi is None else hi
+        with torch.no_grad():
+            for i in range(lo, hi):
+                p, slot = self.params[i], self.slots[i]
+                g = p.grad
+                if g is None:
+                    slot.zero_()
+                elif g.data_ptr() != slot.data_ptr():
+                    slot.copy_(g)
+                else:
+                    continue
+                p.grad = slot
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -121,6 +146,7 @@ class FusedAdam(torch.optim.Optimizer):
             bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
             host = torch.tensor([group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]], dtype=torch.float32)
             self._hyper[gi].copy_(host, non_blocking=True)
+            fb.collect()
             unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2)
         return loss
 

@@ -13,6 +13,7 @@ import torch
 from torch import Tensor
 
 from ._cabi import call, query
+from .gradslot import grad_slot
 from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -80,6 +81,7 @@ class _ConvBNReLU(torch.autograd.Function):
         pooled = empty_nhwc(n, cout, h // 2, w // 2, dtype, dev) if want_pool else None
         call("miseg_bn_relu_fwd", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(saved), _ptr(y), _ptr(pooled))
         ctx.save_for_backward(x0, x1, weight, gamma, raw, y, saved)
+        ctx.param_refs = (weight, gamma, beta)   # the Parameter objects (flat-gradient slots hang off them)
         ctx.cfg = (training, ups0, ups1, want_pool, c0, c1, n, h, w, cout)
         if want_pool:
             return y, pooled
@@ -95,14 +97,20 @@ class _ConvBNReLU(torch.autograd.Function):
         gy = None if gy is None else as_nhwc(gy.to(dtype))
         gpool = None if gpool is None else as_nhwc(gpool.to(dtype))
         graw = empty_nhwc(n, cout, h, w, dtype, dev)
-        ggamma = torch.empty(cout, dtype=torch.float32, device=dev)
-        gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+        pw, pg, pb = ctx.param_refs
+        ggamma, gbeta = grad_slot(pg), grad_slot(pb)   # written in place when the flat gradient buffer has an open slot
+        if ggamma is None:
+            ggamma = torch.empty(cout, dtype=torch.float32, device=dev)
+        if gbeta is None:
+            gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
         call("miseg_bn_relu_bwd", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
              int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel())
         gw = None
         if ctx.needs_input_grad[2]:
-            gw = torch.empty_like(weight)
+            gw = grad_slot(pw)
+            if gw is None:
+                gw = torch.empty_like(weight)
             ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
             call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
                  _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
