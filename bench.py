@@ -164,9 +164,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
+    t_host = time.perf_counter() - t0   # host-side enqueue time (each step ends with one blocking scalar fetch)
     barrier()
     dt = time.perf_counter() - t0
-    note(f"timed {args.steps} steps in {dt:.3f} s")
+    note(f"timed {args.steps} steps in {dt:.3f} s (host loop {t_host:.3f} s)")
     _cabi.TIMER = None
     drv.close()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)

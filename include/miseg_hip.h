@@ -99,8 +99,9 @@ int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S
  * feature sample src[m] (int32[M]) with flip mask flips[m].
  * feat: NHWC [B,H,W,C] (dt).  w: fp32 [S][K][C], b: fp32 [S][K].  T = softmax temperature.
  * local  fwd: prob fp32 [S][M][K][H][W] (NCHW per sub-head).
- * local  bwd: gprob same shape -> gfeat NHWC [B,H,W,C] (dt, ACCUMULATES into existing values),
- *             gw [S][K][C], gb [S][K] (overwritten).
+ * local  bwd: gprob same shape -> gfeat NHWC [B,H,W,C] (dt): rows src[m] are OVERWRITTEN with the gradient, all
+ *             other rows are left as they are (callers pass a zeroed buffer); src[] must be pairwise distinct (each
+ *             gfeat element then has one writer -- the epocher's src is an arange); gw [S][K][C], gb [S][K] overwritten.
  * global fwd: prob fp32 [S][M][K]; bwd likewise (flips are irrelevant under global pooling).
  * ------------------------------------------------------------------------------------------ */
 int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,

@@ -56,6 +56,84 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_kernel(const T* __restrict
     }
 }
 
+// Register-resident variant for K <= 32 (KP = K rounded up to a multiple of 4): the K logits of a pixel live in VGPRs,
+// the head weights arrive as scalar operands (wave-uniform addresses -> scalar cache), so a sub-head costs K*C FMAs per
+// pixel and no LDS traffic at all (the LDS-column kernel above spends ~15 LDS operations per logit update).
+// Logits accumulate through explicit FMAs (channel order) and the softmax multiplies by one reciprocal per pixel: results
+// differ from head_local_fwd_kernel by an ulp or two, inside the parity tolerance of tests/test_gpu_mi.py.
+template <typename T, int KP, int PPT>
+__global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __restrict__ feat, int H, int W, int C,
+                                                                 const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
+                                                                 int M, const float* __restrict__ w, const float* __restrict__ b, int S,
+                                                                 int K, float invT, float* __restrict__ prob) {
+    // PPT consecutive pixels per thread (PPT = 4 needs HW % 4 == 0): every (s,k) plane is then written in 16-byte pieces,
+    // 4 KB contiguous per block, instead of 100 interleaved 1 KB streams
+    const int tid = threadIdx.x, HW = H * W;
+    const int m = blockIdx.y;
+    const int pix0 = (blockIdx.x * kHT + tid) * PPT;
+    const bool live = pix0 < HW;
+    const int f = flips ? flips[m] : 0;
+    const T* fp[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int pix = live ? pix0 + j : 0, h = pix / W, wq = pix % W;
+        fp[j] = feat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+    }
+    for (int s = 0; s < S; ++s) {
+        const float* ws = w + (size_t)s * K * C;
+        float z[PPT][KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const float bv = b[s * K + min(k, K - 1)];
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) z[j][k] = bv;
+        }
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            float fr[PPT][4];
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                Vec4<T> fv = *reinterpret_cast<const Vec4<T>*>(fp[j] + c0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fr[j][i] = fv.get(i);
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const float* wr = ws + (size_t)min(k, K - 1) * C + c0;
+                const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) z[j][k] = fmaf(w3, fr[j][3], fmaf(w2, fr[j][2], fmaf(w1, fr[j][1], fmaf(w0, fr[j][0], z[j][k]))));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            float mx = -3.4e38f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                z[j][k] *= invT;
+                if (k < K) mx = fmaxf(mx, z[j][k]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                z[j][k] = expf(z[j][k] - mx);
+                if (k < K) sum += z[j][k];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) z[j][k] *= inv;
+        }
+        if (live) {
+            float* out = prob + (((size_t)s * M + m) * K) * HW + pix0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                if (k < K) {
+                    if (PPT == 4) *reinterpret_cast<float4*>(out + (size_t)k * HW) = make_float4(z[0][k], z[1][k], z[2][k], z[3][k]);
+                    else out[(size_t)k * HW] = z[0][k];
+                }
+        }
+    }
+}
+
 // Backward pass A: dz = p*(g - <g,p>)/T  (written to ws, same [S][M][K][H][W] layout) and
 // gfeat[src[m]][flip(h,w)][c] += sum_{s,k} W[s][k][c] dz[s][k].
 template <typename T>
@@ -307,7 +385,9 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
             for (int q = 0; q < 64; ++q) a += dzs[tid * DZS + q];
             gbacc += a;
         }
-        // ---- phase 2: gfeat tile [64 px][C]: wave wv owns pixel tile wv (16 px)
+        // ---- phase 2: gfeat tile [64 px][C]: wave wv owns pixel tile wv (16 px).  Operands swapped so that D^T comes out:
+        // a lane holds 4 consecutive channels of one pixel -> one 8-byte (bf16) / 16-byte (fp32) store.  Plain stores: every
+        // gfeat element has exactly one writer (distinct src per window, see the entry point) and the buffer arrives zeroed.
         if (gfeat) {
             f32x4 accf[CTM];
 #pragma unroll
@@ -319,20 +399,27 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
                 for (int c = 0; c < CTM; ++c)
                     if (c < CT) {
                         const float bv = wsm[(ks + kq) * WS + min(c * 16 + l15, C - 1)];
-                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accf[c], 0, 0, 0);
+                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, accf[c], 0, 0, 0);
                     }
             }
-            // D[row = pixel kq*4+r][col = channel l15]
+            // D^T[row = channel c*16 + kq*4 + r][col = pixel l15]
+            const int pq = p0 + wv * 16 + l15;
+            if (pq < HW) {
+                const int h = pq / W, wq = pq % W;
+                T* gp = gfeat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pq = p0 + wv * 16 + kq * 4 + r;
-                if (pq < HW) {
-                    const int h = pq / W, wq = pq % W;
-                    T* gp = gfeat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+                for (int c = 0; c < CTM; ++c) {
+                    const int cc = c * 16 + kq * 4;
+                    if (c < CT && cc + 3 < C) {
+                        T pk[4];
 #pragma unroll
-                    for (int c = 0; c < CTM; ++c) {
-                        const int cc = c * 16 + l15;
-                        if (c < CT && cc < C) gp[cc] = from_f32<T>(to_f32(gp[cc]) + accf[c][r]);
+                        for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(accf[c][r]);
+                        if (sizeof(T) == 2) *reinterpret_cast<uint2*>(gp + cc) = *reinterpret_cast<const uint2*>(pk);
+                        else *reinterpret_cast<uint4*>(gp + cc) = *reinterpret_cast<const uint4*>(pk);
+                    } else if (c < CT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (cc + r < C) gp[cc + r] = from_f32<T>(accf[c][r]);
                     }
                 }
             }
@@ -390,6 +477,20 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
     dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
     size_t ldsb = (size_t)K * kHT * 4;
     hipStream_t st = as_stream(stream);
+    if (K <= 32 && (dt == MISEG_F32 || dt == MISEG_BF16)) {
+        const bool quad = (H * W) % 4 == 0 && W % 4 == 0;
+        const dim3 gridq((unsigned)cdiv(H * W, kHT * 4), (unsigned)M);
+#define HLF(TT, KPP)                                                                                                                   \
+    {                                                                                                                                 \
+        if (quad) hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 4>), gridq, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob); \
+        else hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 1>), grid, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob); \
+    }
+#define HLF_K(TT) switch ((K + 3) / 4) { case 1: HLF(TT, 4); break; case 2: HLF(TT, 8); break; case 3: HLF(TT, 12); break; case 4: HLF(TT, 16); break; \
+                                         case 5: HLF(TT, 20); break; case 6: HLF(TT, 24); break; case 7: HLF(TT, 28); break; default: HLF(TT, 32); break; }
+        if (dt == MISEG_F32) HLF_K(float) else HLF_K(bf16)
+#undef HLF_K
+#undef HLF
+    } else
     if (dt == MISEG_F32)
         hipLaunchKernelGGL(head_local_fwd_kernel<float>, grid, dim3(kHT), ldsb, st, (const float*)feat, (int)H, (int)W, (int)C, src,
                            flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob);
