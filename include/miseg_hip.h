@@ -104,9 +104,11 @@ int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S
  *             gfeat element then has one writer -- the epocher's src is an arange); gw [S][K][C], gb [S][K] overwritten.
  * global fwd: prob fp32 [S][M][K]; bwd likewise (flips are irrelevant under global pooling).
  * ------------------------------------------------------------------------------------------ */
+/* simplex_violations (optional, needs K <= 32): += number of (sub-head, sample, pixel) positions whose K probabilities
+ * do not sum to 1 within simplex_tol -- the consumer's `assert simplex(prob)` (ref iic_loss.py:28-29) for free. */
 int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                          const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b,
-                         int64_t S, int64_t K, float T, float* prob);
+                         int64_t S, int64_t K, float T, float* prob, float simplex_tol, int32_t* simplex_violations);
 int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K);
 int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                          const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S,

@@ -65,7 +65,8 @@ template <typename T, int KP, int PPT>
 __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __restrict__ feat, int H, int W, int C,
                                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                  int M, const float* __restrict__ w, const float* __restrict__ b, int S,
-                                                                 int K, float invT, float* __restrict__ prob) {
+                                                                 int K, float invT, float* __restrict__ prob, float tol,
+                                                                 int32_t* __restrict__ viol) {
     // PPT consecutive pixels per thread (PPT = 4 needs HW % 4 == 0): every (s,k) plane is then written in 16-byte pieces,
     // 4 KB contiguous per block, instead of 100 interleaved 1 KB streams
     const int tid = threadIdx.x, HW = H * W;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
         const int pix = live ? pix0 + j : 0, h = pix / W, wq = pix % W;
         fp[j] = feat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
     }
+    int nbad = 0;
     for (int s = 0; s < S; ++s) {
         const float* ws = w + (size_t)s * K * C;
         float z[PPT][KP];
@@ -119,8 +121,13 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
                 if (k < K) sum += z[j][k];
             }
             const float inv = 1.0f / sum;
+            float ps = 0.f;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) z[j][k] *= inv;
+            for (int k = 0; k < KP; ++k) {
+                z[j][k] *= inv;
+                if (k < K) ps += z[j][k];
+            }
+            nbad += !(fabsf(ps - 1.f) <= tol);   // the caller's simplex assertion, evaluated while the values are in registers
         }
         if (live) {
             float* out = prob + (((size_t)s * M + m) * K) * HW + pix0;
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
                 }
         }
     }
+    if (viol && live && nbad) atomicAdd(viol, nbad);
 }
 
 // Backward pass A: dz = p*(g - <g,p>)/T  (written to ws, same [S][M][K][H][W] layout) and
@@ -471,9 +479,10 @@ using namespace miseg;
 
 extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
-                                    int64_t K, float T, float* prob) {
+                                    int64_t K, float T, float* prob, float simplex_tol, int32_t* simplex_violations) {
     MISEG_REQUIRE(feat && src && w && b && prob, "head_local_fwd: null pointer");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && K > 0 && K <= 64 && M > 0 && S > 0 && H > 0 && W > 0, "head_local_fwd: need C%%4==0, K<=64");
+    MISEG_REQUIRE(simplex_violations == nullptr || K <= 32, "head_local_fwd: the fused simplex check needs K <= 32");
     dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
     size_t ldsb = (size_t)K * kHT * 4;
     hipStream_t st = as_stream(stream);
@@ -482,8 +491,8 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
         const dim3 gridq((unsigned)cdiv(H * W, kHT * 4), (unsigned)M);
 #define HLF(TT, KPP)                                                                                                                   \
     {                                                                                                                                 \
-        if (quad) hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 4>), gridq, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob); \
-        else hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 1>), grid, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob); \
+        if (quad) hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 4>), gridq, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
+        else hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 1>), grid, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
     }
 #define HLF_K(TT) switch ((K + 3) / 4) { case 1: HLF(TT, 4); break; case 2: HLF(TT, 8); break; case 3: HLF(TT, 12); break; case 4: HLF(TT, 16); break; \
                                          case 5: HLF(TT, 20); break; case 6: HLF(TT, 24); break; case 7: HLF(TT, 28); break; default: HLF(TT, 32); break; }

@@ -277,8 +277,10 @@ class _LocalHead(torch.autograd.Function):
         m = src.numel()
         w, b = w.contiguous().float(), b.contiguous().float()
         prob = torch.empty(s, m, k, h, wd, dtype=torch.float32, device=feat.device)
+        viol = torch.zeros((), dtype=torch.int32, device=feat.device) if k <= 32 else None
+        _LocalHead.last_violations = viol
         call("miseg_head_local_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), _ptr(b),
-             s, k, float(temperature), _ptr(prob), work=(2.0 * s * k * c * m * h * wd, (s * k * 4.0 + c * feat.element_size()) * m * h * wd),
+             s, k, float(temperature), _ptr(prob), 2e-4, _ptr(viol), work=(2.0 * s * k * c * m * h * wd, (s * k * 4.0 + c * feat.element_size()) * m * h * wd),
              tag=f"head_local_fwd[c{c}]")
         ctx.save_for_backward(feat, w, src, flips, prob)
         ctx.temperature = float(temperature)
@@ -302,7 +304,15 @@ class _LocalHead(torch.autograd.Function):
 
 
 def local_head(feat: Tensor, w: Tensor, b: Tensor, src: Tensor, flips: Optional[Tensor], temperature: float = 1.0) -> Tensor:
-    return _LocalHead.apply(feat, w, b, src, flips, float(temperature))
+    """prob[S, M, K, H, W].  The kernel also counts the positions whose K probabilities do not sum to one; the count rides
+    on the result (``_miseg_simplex`` = (axis, device counter, tensor version)) so that a later ``checks.assert_simplex`` of
+    this very tensor costs nothing."""
+    _LocalHead.last_violations = None
+    prob = _LocalHead.apply(feat, w, b, src, flips, float(temperature))
+    if _LocalHead.last_violations is not None:
+        prob._miseg_simplex = (2, _LocalHead.last_violations, prob._version)
+        _LocalHead.last_violations = None
+    return prob
 
 
 class _GlobalHead(torch.autograd.Function):

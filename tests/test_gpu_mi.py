@@ -270,3 +270,27 @@ def test_simplex_checks_immediate_and_deferred():
     with pytest.raises(AssertionError):
         pend.fetch()
     assert pend.fetch() == {}   # flags are consumed
+
+
+def test_local_head_counts_simplex_violations_for_free():
+    """ops.local_head's kernel evaluates the consumer's ``assert simplex`` (ref iic_loss.py:28-29) while the
+    probabilities are in registers; checks.simplex_violations must hand back that counter for the untouched tensor,
+    and it must agree with the stand-alone check."""
+    from miseg_amd import checks
+    feat = torch.randn(4, 16, 12, 20, device=DEV).to(memory_format=torch.channels_last)
+    w, b = torch.randn(3, 6, 16, device=DEV), torch.randn(3, 6, device=DEV)
+    src = torch.arange(4, dtype=torch.int32, device=DEV)
+    prob = ops().local_head(feat, w, b, src, None, 1.0)
+    fused = checks.simplex_violations(prob, 2)
+    assert fused is prob._miseg_simplex[1] and int(fused) == 0
+    del prob._miseg_simplex
+    assert int(checks.simplex_violations(prob, 2)) == 0
+    b_bad = b.clone()
+    b_bad[1, 2] = float("nan")
+    bad = ops().local_head(feat, w, b_bad, src, None, 1.0)
+    n_fused = int(checks.simplex_violations(bad, 2))
+    del bad._miseg_simplex
+    assert n_fused == int(checks.simplex_violations(bad, 2)) == 4 * 12 * 20   # every pixel of sub-head 1
+    bad2 = ops().local_head(feat, w, b, src, None, 1.0)
+    bad2[0, 0, 0, 0, 0] += 0.5          # in-place edit bumps the version: the cached counter no longer applies
+    assert int(checks.simplex_violations(bad2, 2)) == 1
