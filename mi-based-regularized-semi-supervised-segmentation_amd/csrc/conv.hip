@@ -490,6 +490,7 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_wgrad_kernel(ConvSrc src, int 
 // half touches tile the 64 banks exactly) and fragments come out of ds_read_b64_tr_b16 (hardware 4x16 transpose):
 // lane 4q+p of a 16-lane group supplies (pixel 8g+q, channels 4p..4p+3) and receives its channel's 4 pixels.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
 
 __device__ __forceinline__ bf16x8_t tr_frag(const short* blk_px0, int q, int p) {
@@ -512,12 +513,16 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
     const int split = blockIdx.x, ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
     const int tilesC = (W + WG_TW - 1) / WG_TW, tilesR = (H + WG_TH - 1) / WG_TH;
     const int ntiles = N * tilesR * tilesC;
-    f32x4 acc[2][18];
+    // v_mfma_f32_32x32x16_bf16: one 32 co x 32 ci tile per tap (16 fp32 per lane), k = 16 pixels per step.  Lane map:
+    // operand row/col = lane & 31, k-half (8 pixels) = lane >> 5; the 16-lane groups of ds_read_b64_tr_b16 are therefore
+    // (channels 0-15 | 16-31) x (pixels 0-7 | 8-15) = (g16 & 1, g16 >> 1).  Half the LDS bytes per flop of 16x16x32.
+    f32x16 acc[9];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 9; ++b)
 #pragma unroll
-        for (int b = 0; b < 18; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int g16 = lane >> 4, chh = g16 & 1, pxh = g16 >> 1;
 
     // next tile's operands travel global -> registers while the current tile is on the matrix cores
     constexpr int NG = NPX * 4 / kCT, NI = (NIPX * 4 + kCT - 1) / kCT;
@@ -570,36 +575,32 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
             const int row = wv * 2 + rr;
-            const bf16x8_t a0 = tr_frag(Gs + (0 * NPX + row * WG_TW + g8) * 16, q, p4);
-            const bf16x8_t a1 = tr_frag(Gs + (1 * NPX + row * WG_TW + g8) * 16, q, p4);
+            const short* gb = Gs + (chh * NPX + row * WG_TW + 8 * pxh) * 16;
+            const bf16x8_t a0 = tr_frag(gb, q, p4), a1 = tr_frag(gb + 16 * 16, q, p4);     // pixels 0-15 | 16-31 of the row
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                const int ipx = (row + ky) * IW + g8 + kx;
-                const bf16x8_t b0 = tr_frag(Is + (0 * NIPX + ipx) * 16, q, p4);
-                const bf16x8_t b1 = tr_frag(Is + (1 * NIPX + ipx) * 16, q, p4);
-                acc[0][tap * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[0][tap * 2 + 0], 0, 0, 0);
-                acc[0][tap * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[0][tap * 2 + 1], 0, 0, 0);
-                acc[1][tap * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[1][tap * 2 + 0], 0, 0, 0);
-                acc[1][tap * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[1][tap * 2 + 1], 0, 0, 0);
+                const short* ib = Is + (chh * NIPX + (row + ky) * IW + kx + 8 * pxh) * 16;
+                const bf16x8_t b0 = tr_frag(ib, q, p4), b1 = tr_frag(ib + 16 * 16, q, p4);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tap], 0, 0, 0);
             }
         }
     }
     // reduce the 4 waves in LDS (fixed order), write partial [split][co 32][tap 9][ci 32]
+    // D[row = co = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = ci = lane & 31]
     float* Ds = reinterpret_cast<float*>(wsm_raw);  // 32 x 288 floats = 36.9 KB (fits: G+I tiles are 38.1 KB)
     for (int w = 0; w < 4; ++w) {
         __syncthreads();
         if (wv == w) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int b = 0; b < 18; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = a * 16 + kq * 4 + r, col = (b / 2) * 32 + (b % 2) * 16 + l15;
-                        if (w == 0) Ds[co * 288 + col] = acc[a][b][r];
-                        else Ds[co * 288 + col] += acc[a][b][r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = tap * 32 + (lane & 31);
+                    if (w == 0) Ds[co * 288 + col] = acc[tap][r];
+                    else Ds[co * 288 + col] += acc[tap][r];
+                }
         }
     }
     __syncthreads();
