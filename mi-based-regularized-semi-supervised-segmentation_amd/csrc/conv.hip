@@ -17,7 +17,8 @@ constexpr int CK = 32;    // input channels per LDS chunk
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
-    static constexpr int CKP = 40;   // padded channel stride (elements): 80 B rows, 16-B aligned, conflict-free b128
+    static constexpr int CKP = 40;   // padded channel stride (elements): 80 B rows, 16-B aligned (2-way on ds_read_b128's lane groups)
+    static constexpr int KP = 48;    // 96 B rows: the 16-lane groups of ds_read_b128 hit 64 distinct banks (conv3x3_kernel)
     static constexpr int VEC = 8;    // elements per 16-byte vector
     typedef s16x8 Frag;
     static __device__ __forceinline__ Frag load(const bf16* base, int kq) { return *reinterpret_cast<const Frag*>(base + 8 * kq); }
@@ -27,6 +28,7 @@ template <> struct Mma<bf16> {
 };
 template <> struct Mma<float> {
     static constexpr int CKP = 34;   // 2m+kq bank pattern: conflict-free ds_read_b32 gathers
+    static constexpr int KP = 34;
     static constexpr int VEC = 4;
     struct Frag { float v[8]; };
     static __device__ __forceinline__ Frag load(const float* base, int kq) {
@@ -57,11 +59,13 @@ template <typename T, int COT, int TW>
 __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
                                                         T* __restrict__ out, float* __restrict__ stats) {
     typedef Mma<T> MM;
-    constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
+    constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
+    constexpr int KP = MM::KP;                              // LDS stride of one pixel / one weight row (elements)
     constexpr int IW = TW + 2, IH = TH + 2;
+    constexpr int NIS = (IH * IW * (CK / VEC) + kCT - 1) / kCT, NWS = (9 * COT * (CK / VEC) + kCT - 1) / kCT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][CKP]
-    T* Ws = Is + IH * IW * CKP;                            // [9][COT][CKP]
+    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][KP]
+    T* Ws = Is + IH * IW * KP;                             // [9][COT][KP]
     const int Cin = src.C0 + src.C1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int tilesC = (W + TW - 1) / TW, tilesR = (H + TH - 1) / TH;
@@ -74,43 +78,68 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
-        __syncthreads();
-        // ---- input tile (halo 1), VEC channels per thread-iteration
-        for (int idx = tid; idx < IH * IW * (CK / VEC); idx += kCT) {
+    // One 32-channel chunk of the haloed input tile and of the weights is in flight in registers while the previous
+    // chunk is on the matrix cores (the block is alone on its CU: 1 wave per SIMD, so nothing else hides the latency).
+    uint4 pin[NIS], pwt[NWS];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NIS; ++j) {
+            const int idx = tid + kCT * j;
             const int v = idx % (CK / VEC), px = idx / (CK / VEC), ix = px % IW, iy = px / IW;
             const int h = h0 - 1 + iy, w = w0 - 1 + ix, c = c0 + v * VEC;
-            T* dst = Is + (iy * IW + ix) * CKP + v * VEC;
-            if (h < 0 || h >= H || w < 0 || w >= W || c >= Cin) { zero_vec<T>(dst); continue; }
-            const T* sp;
-            if (c < src.C0) {
-                const int hs = H >> src.ups0, wsz = W >> src.ups0;
-                sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
-            } else {
-                const int hs = H >> src.ups1, wsz = W >> src.ups1;
-                sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
+            uint4 val = zero4;
+            if (idx < IH * IW * (CK / VEC) && h >= 0 && h < H && w >= 0 && w < W && c < Cin) {
+                const T* sp;
+                if (c < src.C0) {
+                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                    sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
+                } else {
+                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                    sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
+                }
+                val = *reinterpret_cast<const uint4*>(sp);
             }
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sp);
+            pin[j] = val;
         }
-        // ---- weight chunk: packed [tap][Cout][Cin]
-        for (int idx = tid; idx < 9 * COT * (CK / VEC); idx += kCT) {
+#pragma unroll
+        for (int j = 0; j < NWS; ++j) {
+            const int idx = tid + kCT * j;
             const int v = idx % (CK / VEC), co = (idx / (CK / VEC)) % COT, tap = idx / ((CK / VEC) * COT);
             const int c = c0 + v * VEC;
-            T* dst = Ws + (tap * COT + co) * CKP + v * VEC;
-            if (co0 + co >= Cout || c >= Cin) { zero_vec<T>(dst); continue; }
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
+            uint4 val = zero4;
+            if (idx < 9 * COT * (CK / VEC) && co0 + co < Cout && c < Cin)
+                val = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
+            pwt[j] = val;
+        }
+    };
+    // every fragment read below is one of these two bases plus a compile-time offset (an instruction immediate)
+    const T* Ib = Is + ((wv * 4) * IW + l15) * KP;
+    const T* Wb = Ws + l15 * KP;
+    fetch(0);
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();                       // previous chunk's MFMAs are done with Is / Ws
+#pragma unroll
+        for (int j = 0; j < NIS; ++j) {
+            const int idx = tid + kCT * j;
+            if (idx < IH * IW * (CK / VEC)) *reinterpret_cast<uint4*>(Is + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pin[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NWS; ++j) {
+            const int idx = tid + kCT * j;
+            if (idx < 9 * COT * (CK / VEC)) *reinterpret_cast<uint4*>(Ws + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pwt[j];
         }
         __syncthreads();
-#pragma unroll 1
+        if (c0 + CK < Cin) fetch(c0 + CK);
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             typename MM::Frag bf[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bf[t] = MM::load(Ws + (tap * COT + t * 16 + l15) * CKP, kq);
+            for (int t = 0; t < NT; ++t) bf[t] = MM::load(Wb + (tap * COT + t * 16) * KP, kq);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const int row = wv * 4 + m / MTR + ky, col = (m % MTR) * 16 + l15 + kx;
-                typename MM::Frag af = MM::load(Is + (row * IW + col) * CKP, kq);
+                typename MM::Frag af = MM::load(Ib + ((m / MTR + ky) * IW + (m % MTR) * 16 + kx) * KP, kq);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);   // D^T: rows = channels, cols = pixels
             }
@@ -727,7 +756,7 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
     hipStream_t st = as_stream(stream);
 #define LAUNCH(TT, COT, TWW)                                                                                              \
     {                                                                                                                     \
-        size_t lb = ((size_t)(TH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::CKP * sizeof(TT);                                  \
+        size_t lb = ((size_t)(TH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);                                   \
         hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
         hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
                            (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats);                                       \
