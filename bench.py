@@ -110,6 +110,10 @@ def main():
                     help="local-MI contraction arithmetic (default: bf16x3 with --dtype bfloat16, fp32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the device half of the step as one captured hipGraph (miseg_amd.graph); at the cfg2 shape the step is "
+                         "GPU-bound either way (13.6 ms replayed vs 13.5 ms eager), so eager -- with per-kernel events inside the "
+                         "timed region -- stays the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,25 +145,33 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"built step: world={world} LB=UB={args.lb} {args.size}x{args.size} {args.dtype}")
-    # Per-kernel HIP-event timing costs host time (two events per call), so the full table is taken over the last
-    # warm-up steps and only the dominant kernel is timed inside the timed region (that figure feeds `roofline`).
+    # Per-kernel HIP-event timing costs host time (two events per call) and cannot be recorded inside a replayed hipGraph,
+    # so the full table is taken over the last EAGER warm-up steps; inside the timed region only the dominant kernel is
+    # timed (eager runs) -- with the step graph on (default on one GPU) the warm-up figure of that kernel feeds `roofline`.
+    use_graph = world == 1 and args.graph and hasattr(ep, "enable_step_graph")
+    eager_warm = max(1, args.warmup - 2) if use_graph else args.warmup
+    if use_graph:
+        ep.enable_step_graph(warmup=eager_warm)
     survey, timer = None, None
     use_timer = rank == 0 and not args.no_kernel_timer
-    survey_steps = min(2, args.warmup) if use_timer else 0
+    survey_steps = min(2, eager_warm) if use_timer else 0
     for i in range(args.warmup):
-        if use_timer and i == args.warmup - survey_steps:
+        if use_timer and i == eager_warm - survey_steps:
             torch.cuda.synchronize()
             survey = _cabi.KernelTimer()
             _cabi.TIMER = survey
+        if i == eager_warm:
+            _cabi.TIMER = None
         drv.step()
-        note(f"warmup step {i} done")
+        note(f"warmup step {i} done" + (" (graph)" if use_graph and i >= eager_warm else ""))
     _cabi.TIMER = None
     table = []
     if survey is not None and survey.records:
         torch.cuda.synchronize()
         table = sorted(survey.summary().items(), key=lambda kv: -kv[1]["total_ms"])
-        timer = _cabi.KernelTimer(only={table[0][0]})
-        _cabi.TIMER = timer
+        if not use_graph:
+            timer = _cabi.KernelTimer(only={table[0][0]})
+            _cabi.TIMER = timer
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -185,10 +197,15 @@ def main():
             "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
                                    f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
                        "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "step_graph": bool(use_graph)},
         }
-        if timer is not None and timer.records:
-            name, top = next(iter(timer.summary().items()))
+        if table:
+            if timer is not None and timer.records:
+                name, top = next(iter(timer.summary().items()))
+                calls_per_step, timed_in = top["calls"] / args.steps, "timed region (eager)"
+            else:   # graph replay: per-kernel events are not recordable inside the graph -> eager warm-up steps of this process
+                name, top = table[0]
+                calls_per_step, timed_in = top["calls"] / survey_steps, "eager warm-up steps (timed region replays a hipGraph)"
             # which matrix pipe the kernel runs on: local-MI follows --mi-precision (bf16x3 = three bf16 MFMAs per
             # algorithmic product, priced against the plain bf16 dense peak), head backward is fp32 MFMA, convs follow --dtype
             mfma_f32 = name.startswith("head_local_bwd") or (name.startswith("iic_local") and mi_prec == "fp32") or \
@@ -196,7 +213,7 @@ def main():
             tf = top["flops_per_call"] / (top["avg_ms"] * 1e-3) / 1e12
             peak = PEAK["mfma_f32"] if mfma_f32 else PEAK["mfma_bf16"]
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(tf / peak, 4), "traffic": None, "avg_ms": round(top["avg_ms"], 4), "calls_per_step": top["calls"] / args.steps,
+                               "frac": round(tf / peak, 4), "traffic": None, "avg_ms": round(top["avg_ms"], 4), "calls_per_step": calls_per_step, "events_from": timed_in,
                                "mfma_dtype": "f32" if mfma_f32 else "bf16",
                                "hbm_achieved_GBps": round(top["bytes_per_call"] / (top["avg_ms"] * 1e-3) / 1e9, 1)}
             out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:10]}

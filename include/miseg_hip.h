@@ -172,6 +172,11 @@ int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_
  * ------------------------------------------------------------------------------------------ */
 int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w_oihw, int64_t Cout, int64_t Cin, int kind,
                                int64_t ci_begin, int64_t ci_count, void* packed);
+/* the same for many layers in ONE launch: jobs_dev = device array of njobs records
+ *   struct miseg_pack_job { const float* w_oihw; void* packed; int32_t Cout, Cin, kind, ci_begin, ci_count, first_block; }  (40 bytes)
+ * job j owns blocks [first_block[j], first_block[j+1]) of 256 elements each (first_block[0] = 0, ascending);
+ * total_blocks = first_block of a virtual job njobs.  All jobs share dt. */
+int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void* jobs_dev, int64_t njobs, int64_t total_blocks);
 /* number of per-block (sum, sumsq) partial rows conv3x3_fwd writes: stats_partials = fp32[parts][2][Cout] */
 int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
 int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,

@@ -422,6 +422,29 @@ __global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, in
     }
 }
 
+// All conv weights of a step in one launch: job j packs like pack_w_kernel; blocks [first_block[j], first_block[j+1]) belong to it.
+struct PackJob {            // mirrors miseg_pack_job (include/miseg_hip.h)
+    const float* w;
+    void* packed;
+    int32_t Cout, Cin, kind, ci_begin, ci_count, first_block;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_w_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                       // last job whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob jb = jobs[lo];
+    const int Nn = jb.kind ? jb.ci_count : jb.Cout, Kk = jb.kind ? jb.Cout : jb.Cin, total = 9 * Nn * Kk;
+    const int e = ((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int k = e % Kk, nn = (e / Kk) % Nn, tap = e / (Kk * Nn), ky = tap / 3, kx = tap % 3;
+    const float v = !jb.kind ? jb.w[(((size_t)nn * jb.Cin + k) * 3 + ky) * 3 + kx]
+                             : jb.w[(((size_t)k * jb.Cin + jb.ci_begin + nn) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    reinterpret_cast<T*>(jb.packed)[e] = from_f32<T>(v);
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // gw[co][ci][ky][kx] = sum_{n,h,w} gout[n,h,w,co] * in[n,h+ky-1,w+kx-1,ci]   (fp32 MFMA, split over pixels)
 // block = (co tile 32, ci chunk 32, split); wave = 2 of the tile's 8 rows; acc 2 x 18 tiles.
@@ -726,6 +749,18 @@ extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, 
         hipLaunchKernelGGL(pack_w_kernel<bf16>, dim3(nb), dim3(256), 0, as_stream(stream), w, (int)Cout, (int)Cin, kind, (int)ci_begin, (int)ci_count, (bf16*)packed);
     else return fail(MISEG_E_INVALID, "pack_conv3x3_weights: bad dtype");
     MISEG_LAUNCH_CHECK("pack_w_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void* jobs_dev, int64_t njobs, int64_t total_blocks) {
+    MISEG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_conv3x3_weights_multi: bad args");
+    static_assert(sizeof(PackJob) == 40, "PackJob layout must match miseg_pack_job");
+    if (dt == MISEG_F32)
+        hipLaunchKernelGGL(pack_w_multi_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), (const PackJob*)jobs_dev, (int)njobs);
+    else if (dt == MISEG_BF16)
+        hipLaunchKernelGGL(pack_w_multi_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), (const PackJob*)jobs_dev, (int)njobs);
+    else return fail(MISEG_E_INVALID, "pack_conv3x3_weights_multi: bad dtype");
+    MISEG_LAUNCH_CHECK("pack_w_multi_kernel");
     return MISEG_OK;
 }
 

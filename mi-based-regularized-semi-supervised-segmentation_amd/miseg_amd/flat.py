@@ -69,6 +69,7 @@ class FlatBuffers:
                 p._miseg_grad_claimed = True   # slots open at zero_grad()
                 self.slots.append(gview)
         self.flat_param, self.flat_grad = flat_p, flat_g
+        unet_ops.PACK_CACHE.invalidate()
 
     def ensure(self) -> None:
         if not self.valid():
@@ -109,6 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m: List[Optional[Tensor]] = [None] * len(self.param_groups)
         self._v: List[Optional[Tensor]] = [None] * len(self.param_groups)
         self._hyper: List[Optional[Tensor]] = [None] * len(self.param_groups)
+        self._hyper_host: List[Optional[Tensor]] = []
         self._pending_state: Optional[dict] = None
 
     @property
@@ -132,22 +134,45 @@ class FusedAdam(torch.optim.Optimizer):
             self._pending_state = None
 
     @torch.no_grad()
+    def advance(self) -> None:
+        """Host half of a step: bump the step counters and upload (lr / bias corrections, eps, weight decay) to the device
+        hyper-parameter array.  Kept apart from ``apply`` so that a captured hipGraph of the step (semi_seg.epocher) can
+        replay the device half while the host half runs before every replay."""
+        for gi, group in enumerate(self.param_groups):
+            self._ensure_state(gi)
+            self._steps[gi] += 1
+            t = self._steps[gi]
+            b1, b2 = group["betas"]
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            host = self._hyper_host[gi] if gi < len(self._hyper_host) else None
+            if host is None or host.device.type != "cpu":
+                host = torch.zeros(4, dtype=torch.float32)
+                if self._hyper[gi].is_cuda:
+                    host = host.pin_memory()
+                while len(self._hyper_host) <= gi:
+                    self._hyper_host.append(None)
+                self._hyper_host[gi] = host
+            host[0], host[1], host[2], host[3] = group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]
+            self._hyper[gi].copy_(host, non_blocking=True)
+
+    @torch.no_grad()
+    def apply(self) -> None:
+        """Device half: gather stray gradients into the flat buffer and launch the fused Adam kernel."""
+        for gi, group in enumerate(self.param_groups):
+            fb = self._flats[gi]
+            b1, b2 = group["betas"]
+            fb.collect()
+            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2)
+        unet_ops.PACK_CACHE.invalidate()   # the fp32 masters changed: packed operand copies are stale
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
-            self._ensure_state(gi)
-            fb = self._flats[gi]
-            self._steps[gi] += 1
-            t = self._steps[gi]
-            b1, b2 = group["betas"]
-            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-            host = torch.tensor([group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]], dtype=torch.float32)
-            self._hyper[gi].copy_(host, non_blocking=True)
-            fb.collect()
-            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2)
+        self.advance()
+        self.apply()
         return loss
 
     # ---- torch.optim.Adam-compatible checkpoints (per-parameter exp_avg / exp_avg_sq / step)

@@ -55,9 +55,14 @@ def arange_i32(start: int, stop: int, device) -> Tensor:
     return cached_const(("arange", str(device), start, stop), lambda: torch.arange(start, stop, dtype=torch.int32, device=device))
 
 
+def flip_masks(decisions: Sequence[Sequence[bool]]) -> List[int]:
+    """[[flip_h, flip_w], ...] -> bit masks (bit0 = H, bit1 = W), still on the host."""
+    return [int(bool(fh)) | (int(bool(fw)) << 1) for fh, fw in decisions]
+
+
 def flips_to_tensor(decisions: Sequence[Sequence[bool]], device) -> Tensor:
     """[[flip_h, flip_w], ...] -> int32 bit masks (bit0 = H, bit1 = W)."""
-    return torch.tensor([int(bool(fh)) | (int(bool(fw)) << 1) for fh, fw in decisions], dtype=torch.int32, device=device)
+    return torch.tensor(flip_masks(decisions), dtype=torch.int32, device=device)
 
 
 # ------------------------------------------------------------------------------------------ local MI

@@ -9,6 +9,9 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import struct
+import weakref
+
 import torch
 from torch import Tensor
 
@@ -35,12 +38,95 @@ def stem_input(image: Tensor, dtype) -> Tensor:
     return out
 
 
-def _pack(weight: Tensor, dtype, kind: int, ci_begin: int = 0, ci_count: int = 0) -> Tensor:
+def _pack_now(weight: Tensor, dtype, kind: int, ci_begin: int, ci_count: int, packed: Optional[Tensor] = None) -> Tensor:
     cout, cin = weight.shape[0], weight.shape[1]
-    n = (ci_count if kind else cout) * (cout if kind else cin) * 9
-    packed = torch.empty(n, dtype=dtype, device=weight.device)
+    if packed is None:
+        packed = torch.empty((ci_count if kind else cout) * (cout if kind else cin) * 9, dtype=dtype, device=weight.device)
     call("miseg_pack_conv3x3_weights", _stream(), _DT[dtype], _ptr(weight), cout, cin, kind, ci_begin, ci_count, _ptr(packed))
     return packed
+
+
+_NO_PACK_CACHE = __import__("os").environ.get("MISEG_NO_PACK_CACHE", "0") == "1"
+
+
+class _PackCache:
+    """Operand-layout copies of the conv weights, refreshed once per optimiser step in ONE launch.
+
+    The U-Net asks for ~47 packed weight tensors per step (forward layout + one dgrad layout per concat source); they
+    only change when the optimiser (or anything else that bumps ``epoch`` / the tensor version) rewrites the masters.
+    The first request after such a change re-packs every registered weight with ``miseg_pack_conv3x3_weights_multi``;
+    the rest of the step are dictionary hits.  Only parameters that live in a flat buffer are cached (their storage is
+    stable); anything else (e.g. the zero-padded stem weight) is packed on the spot."""
+
+    def __init__(self):
+        self.epoch = 0            # bumped by FusedAdam.step / FlatBuffers.build / load_state_dict
+        self.entries = {}         # key -> entry list, see get()
+        self.packed_epoch = -1
+        self.jobs_dev = {}        # dtype -> (device job table, njobs, total_blocks, keys)
+        self.dirty = True
+
+    def invalidate(self) -> None:
+        self.epoch += 1
+
+    def get(self, weight: Tensor, dtype, kind: int, cb: int, cs: int) -> Tensor:
+        if getattr(weight, "_miseg_grad_slot", None) is None or not weight.is_cuda or _NO_PACK_CACHE:
+            return _pack_now(weight, dtype, kind, cb, cs)
+        key = (weight.data_ptr(), tuple(weight.shape), dtype, kind, cb, cs)
+        ent = self.entries.get(key)
+        if ent is None or ent[0]() is not weight:
+            # entry: [weakref(weight), dtype, kind, cb, cs, packed, version packed at, epoch packed at]
+            ent = self.entries[key] = [weakref.ref(weight), dtype, kind, cb, cs, _pack_now(weight, dtype, kind, cb, cs),
+                                       weight._version, self.epoch]
+            self.dirty = True
+            return ent[5]
+        if self.packed_epoch != self.epoch:
+            self._repack_all()
+        if ent[6] != weight._version or ent[7] != self.epoch:   # edited in place since / registered after the batch
+            _pack_now(weight, dtype, kind, cb, cs, ent[5])
+            ent[6], ent[7] = weight._version, self.epoch
+        return ent[5]
+
+    def _repack_all(self) -> None:
+        dead = [k for k, ent in self.entries.items() if ent[0]() is None]   # parameters that no longer exist
+        for k in dead:
+            del self.entries[k]
+        if (dead or self.dirty) and torch.cuda.is_current_stream_capturing():
+            # the job table would need a host->device copy, which a capturing stream does not allow: pack one by one
+            for ent in self.entries.values():
+                w = ent[0]()
+                _pack_now(w, ent[1], ent[2], ent[3], ent[4], ent[5])
+                ent[6], ent[7] = w._version, self.epoch
+            self.packed_epoch = self.epoch
+            return
+        if dead or self.dirty:
+            self.jobs_dev = {}
+            by_dtype = {}
+            for ent in self.entries.values():
+                by_dtype.setdefault(ent[1], []).append(ent)
+            for dtype, ents in by_dtype.items():
+                blob, first = bytearray(), 0
+                for ent in ents:
+                    w, packed = ent[0](), ent[5]
+                    blob += struct.pack("<QQiiiiii", w.data_ptr(), packed.data_ptr(), w.shape[0], w.shape[1], ent[2], ent[3], ent[4], first)
+                    first += (packed.numel() + 255) // 256
+                table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(ents[0][5].device)
+                self.jobs_dev[dtype] = (table, len(ents), first, ents)
+            self.dirty = False
+        for dtype, (table, n, blocks, ents) in self.jobs_dev.items():
+            live = [ent[0]() for ent in ents]          # strong references for the duration of the launch
+            call("miseg_pack_conv3x3_weights_multi", _stream(), _DT[dtype], _ptr(table), n, blocks)
+            for ent, w in zip(ents, live):
+                ent[6], ent[7] = w._version, self.epoch
+        self.packed_epoch = self.epoch
+
+
+PACK_CACHE = _PackCache()
+
+
+def _pack(weight: Tensor, dtype, kind: int, ci_begin: int = 0, ci_count: int = 0) -> Tensor:
+    if not kind:
+        ci_begin, ci_count = 0, weight.shape[1]
+    return PACK_CACHE.get(weight, dtype, kind, int(ci_begin), int(ci_count))
 
 
 class _ConvBNReLU(torch.autograd.Function):

@@ -63,12 +63,20 @@ class _Pending:
         self._names: List[str] = []
         self._vals: List[Tensor] = []
         self.checks: list = []
+        self._static = None
 
     def put(self, name: str, value: Tensor) -> None:
         self._names.append(name)
         self._vals.append(value.detach().reshape(()).float())
 
     def fetch(self) -> dict:
+        if self._static is not None:      # values of a replayed step graph: one static device tensor, fixed names and checks
+            names, scalars, items = self._static
+            self._static = None
+            host = scalars.tolist()
+            out = dict(zip(names, host))
+            checks.raise_failed(items, host[len(names):])
+            return out
         if not self._vals and not self.checks:
             return {}
         host = torch.stack(self._vals + [c[0] for c in self.checks]).tolist()
@@ -77,6 +85,15 @@ class _Pending:
         self._names, self._vals = [], []
         checks.raise_failed(items, host[len(out):])
         return out
+
+    def drain(self):
+        """(names, device scalars, check items) recorded so far, cleared -- used while capturing a step graph."""
+        names, vals, items = self._names, self._vals, list(self.checks)
+        self._names, self._vals, self.checks[:] = [], [], []
+        return names, vals, items
+
+    def set_static(self, names, scalars: Tensor, items) -> None:
+        self._static = (names, scalars, items)
 
 
 class EvalEpocher(_num_class_mixin, _Epocher):
@@ -132,6 +149,7 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         assert isinstance(feature_importance, list) and isinstance(feature_importance[0], (int, float)), feature_importance
         self._feature_position, self._feature_importance = feature_position, feature_importance
         self._reducer = None  # set by miseg_amd.ddp.attach() for data-parallel runs
+        self._step_graph = None  # set by enable_step_graph()
 
     def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
         meters.register_meter("lr", AverageValueMeter())
@@ -140,17 +158,38 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         meters.register_meter("sup_dice", UniversalDice(self.num_classes, report_axises=list(range(1, self.num_classes))))
         return meters
 
-    # ---- one optimisation step; returns nothing, leaves device scalars in self._pending
+    # ---- one optimisation step; leaves device scalars in self._pending
     def _step(self, labeled_data, unlabeled_data):
+        # host prelude: unpack the batches, draw the flip decisions (same draws, same order as the per-sample flips at ref :148-149)
         seed = random.randint(0, int(1e7))
         labeled_image, labeled_target, _, _, label_group = self._unzip_data(labeled_data, self._device)
         unlabeled_image, _unlabeled_target, *_ = self._unzip_data(unlabeled_data, self._device)
-        lb, ub = len(labeled_image), len(unlabeled_image)
-        with FixRandomSeed(seed):  # same draws, same order as the per-sample flips at ref :148-149
+        ub = len(unlabeled_image)
+        with FixRandomSeed(seed):
             decisions = self._affine_transformer.decisions(ub)
-        # one host->device copy: [flips of the UB unlabeled samples | UB zeros] (the tf branch is never re-flipped)
-        self._flips2 = ops.flips_to_tensor(list(decisions) + [[False, False]] * ub, labeled_image.device)
-        flips = self._flips2[:ub]
+        # [flips of the UB unlabeled samples | UB zeros] (the tf branch is never re-flipped)
+        flip_masks = ops.flip_masks(list(decisions) + [[False, False]] * ub)
+        graph = self._step_graph
+        if graph is not None and self._reducer is None and labeled_image.is_cuda:
+            inter, union = graph.run(labeled_image, labeled_target, unlabeled_image, flip_masks, seed)
+        else:
+            flips2 = torch.tensor(flip_masks, dtype=torch.int32, device=labeled_image.device)   # one host->device copy
+            self._optimizer.advance() if hasattr(self._optimizer, "advance") else None
+            inter, union = self._device_step(labeled_image, labeled_target, unlabeled_image, flips2, seed)
+        return inter, union, label_group
+
+    def enable_step_graph(self, warmup: int = 3) -> None:
+        """Replay the device half of the iteration as one hipGraph (miseg_amd.graph.StepGraph): the ~560 launches of a
+        step then cost the host one call.  Single-GPU only; data-parallel runs (a GradReducer is attached) stay eager."""
+        from miseg_amd.graph import StepGraph
+        self._step_graph = StepGraph(self, warmup=warmup)
+
+    def _device_step(self, labeled_image: Tensor, labeled_target: Tensor, unlabeled_image: Tensor, flips2: Tensor, seed: int):
+        """Everything of the iteration that runs on the GPU: forward, losses, backward, optimiser kernel, Dice counts.
+        No host synchronisation and no host->device traffic in here (capturable); ``optimizer.advance()`` (host) has run."""
+        lb, ub = len(labeled_image), len(unlabeled_image)
+        self._flips2 = flips2
+        flips = flips2[:ub]
         unlabeled_image_tf = ops.flip(unlabeled_image, flips)
         assert unlabeled_image_tf.shape == unlabeled_image.shape
 
@@ -177,12 +216,15 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         total_loss.backward()
         if self._reducer is not None:
             self._reducer.finish()
-        self._optimizer.step()
+        if hasattr(self._optimizer, "apply"):
+            self._optimizer.apply()
+        else:
+            self._optimizer.step()
         with torch.no_grad():
             self._pending.put("sup_loss", sup_loss)
             self._pending.put("reg_loss", reg_loss)
             _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False)
-        return inter, union, label_group
+        return inter, union
 
     def _run(self, *args, **kwargs) -> EpochResultDict:
         self.meters["lr"].add(get_lrs_from_optimizer(self._optimizer)[0])
@@ -327,8 +369,6 @@ class UDAIICEpocher(IICTrainEpocher):
     @_fused
     def regularization(self, unlabeled_tf_logits: Tensor, unlabeled_logits_tf: Tensor = None, seed: int = None, *args,
                        unlabeled_logits: Tensor = None, flips: Tensor = None, num_unlabeled: int = None, **kwargs):
-        self.meters["iic_weight"].add(self._iic_weight)
-        self.meters["uda_weight"].add(self._cons_weight)
         iic_loss = self._iic(flips, num_unlabeled if num_unlabeled is not None else len(unlabeled_tf_logits))
         cons_loss = self._uda(unlabeled_tf_logits, unlabeled_logits, flips)
         return self._cons_weight * cons_loss + self._iic_weight * iic_loss
@@ -336,3 +376,6 @@ class UDAIICEpocher(IICTrainEpocher):
     def _record(self, host, inter, union, label_group):
         super()._record(host, inter, union, label_group)
         self.meters["uda"].add(host["uda"])
+        # host-side bookkeeping lives here, not in regularization(): that one is part of the captured device step
+        self.meters["iic_weight"].add(self._iic_weight)
+        self.meters["uda_weight"].add(self._cons_weight)

@@ -139,3 +139,40 @@ def test_first_iteration_is_tight(golden, mode):
         np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
         for f in FEATURES:
             np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
+
+
+def test_step_graph_replay_equals_eager_steps():
+    """The captured hipGraph of the device half of an iteration (miseg_amd.graph.StepGraph) must reproduce the eager
+    iterations: same meters and bit-identical parameters after a mix of eager warm-up, capture and replays.
+    Runs in a fresh interpreter: the capture must not follow an eager backward on the default stream in the same process
+    (miseg_amd/graph.py docstring), which the other tests of this session have already done."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import random, sys, torch
+sys.path[:0] = [%r, %r]
+import bench
+from miseg_amd import _cabi, ops
+_cabi.lib(); ops.set_mi_precision("fp32")
+def run(graph):
+    torch.manual_seed(0); random.seed(7)
+    ep, opt = bench.build_step(torch.device("cuda"), 2, 2, 64, "float32", 0)
+    drv = bench.StepDriver(ep)
+    if graph:
+        ep.enable_step_graph(warmup=2)
+    random.seed(11)
+    for _ in range(5):   # graph: 2 eager, 1 capture + replay, 2 replays
+        drv.step()
+    drv.close()
+    return opt.flat.flat_param.detach().clone(), dict(ep.meters.tracking_status()), opt._steps[0]
+p_graph, m_graph, n_graph = run(True)      # first: nothing has run a backward on the default stream yet
+p_eager, m_eager, n_eager = run(False)
+assert n_eager == n_graph == 5, (n_eager, n_graph)
+assert torch.equal(p_eager, p_graph), float((p_eager - p_graph).abs().max())
+assert repr(m_eager) == repr(m_graph), (m_eager, m_graph)   # repr: the unused lr meter is nan in both
+print("GRAPH_EQUALS_EAGER")
+""" % (root, os.path.join(root, "mi-based-regularized-semi-supervised-segmentation_amd"))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "GRAPH_EQUALS_EAGER" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
