@@ -216,6 +216,13 @@ def main():
                                "frac": round(tf / peak, 4), "traffic": None, "avg_ms": round(top["avg_ms"], 4), "calls_per_step": calls_per_step, "events_from": timed_in,
                                "mfma_dtype": "f32" if mfma_f32 else "bf16",
                                "hbm_achieved_GBps": round(top["bytes_per_call"] / (top["avg_ms"] * 1e-3) / 1e9, 1)}
+            try:   # HBM traffic of the same kernel/shape from the committed rocprofv3 PMC passes (not collectable in-process)
+                tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json"))).get(name)
+                if tr and args.lb == 16 and args.ub == 16 and args.size == 256:
+                    out["roofline"]["traffic"] = tr["traffic_bytes"]
+                    out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
+            except (OSError, ValueError):
+                pass
             out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:10]}
         if world == 1 and not args.no_cpu_baseline:
             try:
