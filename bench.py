@@ -220,7 +220,7 @@ def main():
                 tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json"))).get(name)
                 if tr and args.lb == 16 and args.ub == 16 and args.size == 256:
                     out["roofline"]["traffic"] = tr["traffic_bytes"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
+                    out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; calibration notes inside)"
             except (OSError, ValueError):
                 pass
             out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:10]}
