@@ -90,11 +90,14 @@ def cpu_baseline(threads):
                                                         "Up_conv2": OH.init_local_cluster_head(16, 20, 5, seed=4)}, lr=4e-5, weight_decay=1e-5)
     lab, tgt = torch.rand(lb, 1, 256, 256, generator=g), torch.randint(0, 4, (lb, 1, 256, 256), generator=g)
     unl = torch.rand(ub, 1, 256, 256, generator=g)
-    t0 = time.time()
-    OS.train_step(state, lab, tgt, unl, seed=123, mode="udaiic")
+    OS.train_step(state, lab, tgt, unl, seed=122, mode="udaiic")   # untimed: thread pool / allocator warm-up
+    t0, steps = time.time(), 0
+    while steps < 12 and (steps == 0 or time.time() - t0 < 12.0):   # >= ~12 s of CPU work, bounded
+        OS.train_step(state, lab, tgt, unl, seed=123 + steps, mode="udaiic")
+        steps += 1
     dt = time.time() - t0
-    return {"value": round((lb + ub) / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 udaiic train step of the CPU oracle (oracle/step.py), LB=UB={lb}, 256x256, fp32, {dt:.1f} s"}
+    return {"value": round(steps * (lb + ub) / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} udaiic train steps of the CPU oracle (oracle/step.py), LB=UB={lb}, 256x256, fp32, {dt:.1f} s after one warm-up step"}
 
 
 def main():
