@@ -117,7 +117,7 @@ class IIDSegmentationSmallPathLoss(IIDSegmentationLoss):
         checks.raise_if_nan(losses, "IIDSegmentationSmallPathLoss: a patch loss is nan")
         return average_iter(list(losses)) if len(wins) <= 4 else losses.sum() / float(len(wins))
 
-    def forward_heads(self, probs: Tensor, ub: int, mask: Tensor = None) -> Tensor:
+    def forward_heads(self, probs: Tensor, ub: int, mask: Tensor = None, lazy: bool = False):
         """``[self(p[:ub], p[ub:]) for p in probs]`` as one autograd node: probs[S, 2*UB, K, H, W] -> loss[S].
         Same checks and values as S separate calls (ref semi_seg/epocher.py:264-272 loops the sub-heads)."""
         assert probs.requires_grad and probs.dim() == 5 and probs.shape[1] == 2 * ub, probs.shape
@@ -128,6 +128,9 @@ class IIDSegmentationSmallPathLoss(IIDSegmentationLoss):
         wins = _windows(h, w, self._patch_size, self._step_size)
         losses = ops.local_mi_heads(probs, ub, self.padding, wins, self.lamda, mask)   # [S, P]
         checks.raise_if_nan(losses, "IIDSegmentationSmallPathLoss: a patch loss is nan")
+        if lazy:   # mean over sub-heads of the mean over patches, kept symbolic (miseg_amd.lazy): no reduction kernels
+            from miseg_amd.lazy import LinearLoss
+            return LinearLoss.mean(losses)
         return losses.sum(1) / float(len(wins))
 
     def __repr__(self):

@@ -36,7 +36,8 @@ from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterIn
 from deepclustering2.optim import get_lrs_from_optimizer
 from deepclustering2.type import T_loader, T_loss, T_optim
 from deepclustering2.utils import class2one_hot
-from miseg_amd import checks, ops
+from miseg_amd import checks, lazy, ops
+from miseg_amd.lazy import LinearLoss
 from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
 
 _DEBUG_ASSERTS = os.environ.get("MISEG_ASSERTS", "0") == "1"
@@ -65,9 +66,14 @@ class _Pending:
         self.checks: list = []
         self._static = None
 
-    def put(self, name: str, value: Tensor) -> None:
+    def put(self, name: str, value) -> None:
+        """value: a device scalar or a symbolic miseg_amd.lazy.LinearLoss (evaluated with all others at fetch time)."""
         self._names.append(name)
-        self._vals.append(value.detach().reshape(()).float())
+        self._vals.append(value.detach() if isinstance(value, (Tensor, LinearLoss)) else value)
+
+    def device_values(self) -> Tensor:
+        """float32 device vector: the put() values followed by the deferred-check flags (one cat + one mat-vec)."""
+        return lazy.evaluate(self._vals + [c[0] for c in self.checks])
 
     def fetch(self) -> dict:
         if self._static is not None:      # values of a replayed step graph: one static device tensor, fixed names and checks
@@ -79,7 +85,7 @@ class _Pending:
             return out
         if not self._vals and not self.checks:
             return {}
-        host = torch.stack(self._vals + [c[0] for c in self.checks]).tolist()
+        host = self.device_values().tolist()
         out = dict(zip(self._names, host))
         items, self.checks[:] = list(self.checks), []
         self._names, self._vals = [], []
@@ -271,7 +277,7 @@ class UDATrainEpocher(TrainEpocher):
 
     def _uda(self, unlabeled_tf_logits: Tensor, unlabeled_logits: Tensor, flips: Tensor) -> Tensor:
         if isinstance(self._reg_criterion, nn.MSELoss):
-            loss = ops.softmax_mse(unlabeled_tf_logits, unlabeled_logits, flips)  # flip + 2 softmaxes + MSE fused
+            loss = LinearLoss.of(ops.softmax_mse(unlabeled_tf_logits, unlabeled_logits, flips))  # flip + 2 softmaxes + MSE fused
         else:  # e.g. the KL variant (ref trainer.py:137): generic criterion on materialised operands
             loss = self._reg_criterion(unlabeled_tf_logits.softmax(1), ops.flip(unlabeled_logits, flips).softmax(1).detach())
         self._pending.put("uda", loss)
@@ -322,11 +328,11 @@ class IICTrainEpocher(TrainEpocher):
                     from contrastyou.losses.iic_loss import simplex
                     assert simplex(probs.flatten(0, 1))
                 per_head, _, _ = ops.global_mi(probs[:, :ub], probs[:, ub:], criterion.lamb)
-                losses.append(per_head.mean())
+                losses.append(LinearLoss.mean(per_head))
             else:  # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
                 probs = projector.forward_gathered(feature, src, flips2)  # [S, 2UB, K, H, W]
                 if hasattr(criterion, "forward_heads"):   # all sub-heads as one autograd node (gradient lands in one buffer)
-                    losses.append(criterion.forward_heads(probs, ub).mean())
+                    losses.append(criterion.forward_heads(probs, ub, lazy=True))
                 else:
                     losses.append(average_iter([criterion(p[:ub], p[ub:]) for p in probs]))
         reg_loss = weighted_average_iter(losses, self._feature_importance)
