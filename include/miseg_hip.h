@@ -77,6 +77,16 @@ int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const floa
                         const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate, int precision,
                         void* ws, int64_t ws_bytes);
 int64_t miseg_iic_local_bwd_ws_bytes(int64_t K, int64_t pad, int64_t P);
+/* All S sub-heads of a tap in one launch (ref semi_seg/epocher.py:264-272 loops `criterion(p[:ub], p[ub:]) for p in probs`):
+ * probs fp32 [S][2*UB][K][H][W], x_s = probs[s][:UB], y_s = probs[s][UB:]; raw [S][P][T][T][K][K]; grad_raw likewise;
+ * scale [S][P]; gprob like probs.  Workspaces: max of the single-head queries evaluated at P*S and at P (shapes the
+ * batched bf16 kernels do not serve run one sub-head per launch). */
+int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
+                                    int64_t pad, const int32_t* win, int64_t P, float* raw, void* ws, int64_t ws_bytes,
+                                    int precision);
+int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
+                              int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
+                              float* gprob, int accumulate, int precision, void* ws, int64_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Global IIC mutual information, S sub-heads in one launch

@@ -14,6 +14,8 @@ struct JointGeom {
     int planeX, planeY;      // LDS floats per channel plane (odd => conflict-poor gathers)
     int P, G;                // windows, persistent blocks per (window, sub-block)
     int tilesM, sb, tps;     // 16-row tiles of D, sub-blocks per dim, tiles per sub-block
+    int S;                   // sub-heads batched into one launch (bf16 kernels): slot = s * P + p, operands at + s * hs
+    long long hs;            // elements between consecutive sub-heads of x / y
 };
 
 constexpr int kJT = 512;
@@ -36,7 +38,7 @@ struct TileSet {
 
 static inline bool plan_joint(JointGeom& g, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
     g.N = (int)N; g.K = (int)K; g.H = (int)H; g.W = (int)W; g.pad = (int)pad; g.T = 2 * (int)pad + 1;
-    g.Mdim = g.T * g.K; g.P = (int)P;
+    g.Mdim = g.T * g.K; g.P = (int)P; g.S = 1; g.hs = 0;
     g.tilesM = (g.Mdim + 15) / 16;
     const int cap = g.tilesM <= 4 ? 4 : 9;
     g.sb = (g.tilesM + cap - 1) / cap;
@@ -67,7 +69,7 @@ int launch_joint_fwd_bf16(hipStream_t st, const float* x, const float* y, const 
 bool joint_fwd_bf16_supported(const JointGeom& g);
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad);
 size_t local_bwd_bf16_ws_bytes(int64_t K, int64_t pad, int64_t P);
-int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
+int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
                           const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
                           void* ws, int nterms);
 

@@ -604,6 +604,58 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
     return MISEG_OK;
 }
 
+// ---- all S sub-heads of a tap in one launch: probs[S][2*UB][K][H][W], x_s = probs[s][:UB], y_s = probs[s][UB:]
+extern "C" int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
+                                               int64_t pad, const int32_t* win, int64_t P, float* raw, void* ws, int64_t ws_bytes,
+                                               int precision) {
+    MISEG_REQUIRE(probs && win && raw && ws, "iic_local_joint_fwd_heads: null pointer");
+    MISEG_REQUIRE(S > 0 && UB > 0 && K > 0 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_joint_fwd_heads: bad shape");
+    const int64_t hs = 2 * UB * K * H * W, TT = (2 * pad + 1) * (2 * pad + 1);
+    JointGeom g;
+    MISEG_REQUIRE(plan_joint(g, UB, K, H, W, pad, P * S), "iic_local_joint_fwd_heads: K=%ld pad=%ld does not fit LDS", (long)K, (long)pad);
+    if (precision != 0 && joint_fwd_bf16_supported(g)) {
+        MISEG_REQUIRE(ws_bytes >= miseg_iic_local_joint_ws_bytes(UB, K, H, W, pad, P * S), "iic_local_joint_fwd_heads: workspace too small");
+        hipStream_t st = as_stream(stream);
+        const int cap = g.tilesM <= 4 ? 4 : 9;
+        JointGeom gh = g;                    // planned for P*S slots (sets G); the kernel sees P windows x S heads
+        gh.P = (int)P; gh.S = (int)S; gh.hs = hs;
+        launch_joint_fwd_bf16(st, probs, probs + UB * K * H * W, nullptr, gh, win, (float*)ws, precision == 1 ? 3 : 1);
+        MISEG_LAUNCH_CHECK("joint_fwd_bf16_kernel");
+        const int64_t total = P * S * TT * K * K;
+        hipLaunchKernelGGL(joint_reduce_kernel, dim3(reduce_grid(total, g.G)), dim3(256), 0, st, (const float*)ws, g, cap, raw);
+        MISEG_LAUNCH_CHECK("joint_reduce_kernel");
+        return MISEG_OK;
+    }
+    for (int64_t s = 0; s < S; ++s) {        // other shapes / exact fp32: one launch per sub-head
+        const int rc = miseg_iic_local_joint_fwd(stream, probs + s * hs, probs + s * hs + UB * K * H * W, nullptr, UB, K, H, W, pad, win, P,
+                                                 raw + s * P * TT * K * K, ws, ws_bytes, precision);
+        if (rc != MISEG_OK) return rc;
+    }
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
+                                         int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
+                                         float* gprob, int accumulate, int precision, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(probs && win && grad_raw && scale && gprob, "iic_local_bwd_heads: null pointer");
+    MISEG_REQUIRE(S > 0 && UB > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_bwd_heads: bad shape (K<=32)");
+    const int64_t hs = 2 * UB * K * H * W, half = UB * K * H * W, TT = (2 * pad + 1) * (2 * pad + 1);
+    if (precision != 0 && local_bwd_bf16_supported(UB, K, H, W, pad)) {
+        MISEG_REQUIRE(ws && ws_bytes >= (int64_t)local_bwd_bf16_ws_bytes(K, pad, P * S), "iic_local_bwd_heads: workspace too small");
+        launch_local_bwd_bf16(as_stream(stream), probs, probs + half, S, hs, UB, K, H, W, pad, win, P, grad_raw, scale, gprob, gprob + half,
+                              accumulate, ws, precision == 1 ? 3 : 1);
+        MISEG_LAUNCH_CHECK("local_bwd_bf16_kernel");
+        return MISEG_OK;
+    }
+    for (int64_t s = 0; s < S; ++s) {
+        const int rc = miseg_iic_local_bwd(stream, probs + s * hs, probs + s * hs + half, nullptr, UB, K, H, W, pad, win, P,
+                                           grad_raw + s * P * TT * K * K, scale + s * P, gprob + s * hs, gprob + s * hs + half, accumulate,
+                                           precision, ws, ws_bytes);
+        if (rc != MISEG_OK) return rc;
+    }
+    return MISEG_OK;
+}
+
 extern "C" int64_t miseg_iic_local_bwd_ws_bytes(int64_t K, int64_t pad, int64_t P) {
     return (int64_t)local_bwd_bf16_ws_bytes(K, pad, P) + 16;
 }
@@ -631,7 +683,7 @@ extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y,
     hipStream_t st = as_stream(stream);
     if (precision != 0 && mask == nullptr && local_bwd_bf16_supported(N, K, H, W, pad)) {   // bf16 MFMA, hi/lo split (1) or plain (2)
         MISEG_REQUIRE(ws && ws_bytes >= (int64_t)local_bwd_bf16_ws_bytes(K, pad, P), "iic_local_bwd: workspace too small for the bf16 path");
-        launch_local_bwd_bf16(st, x, y, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, precision == 1 ? 3 : 1);
+        launch_local_bwd_bf16(st, x, y, 1, 0, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, precision == 1 ? 3 : 1);
         MISEG_LAUNCH_CHECK("local_bwd_bf16_kernel");
         return MISEG_OK;
     }

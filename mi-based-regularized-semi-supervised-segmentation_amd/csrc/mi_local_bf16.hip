@@ -50,8 +50,10 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
     const int l15 = lane & 15, q = lane >> 4;
     unsigned short* As = Asb + (size_t)pair * NP * aPlane;
 
-    const int slot = blockIdx.y;
-    const int p = slot;                                   // one sub-block only on this path (T*K <= 144)
+    const int slot = blockIdx.y;                          // one sub-block only on this path (T*K <= 144): slot = sub-head * P + window
+    const int shead = slot / g.P, p = slot - shead * g.P;
+    x += (size_t)shead * g.hs;
+    y += (size_t)shead * g.hs;
     const int h0 = win[p * 4 + 0], h1 = win[p * 4 + 1], w0 = win[p * 4 + 2], w1 = win[p * 4 + 3];
     const int tr = (h1 - h0 + BRB - 1) / BRB, tc = (w1 - w0 + BKW - 1) / BKW;
     const int nItems = g.N * tr * tc;
@@ -249,7 +251,7 @@ bool joint_fwd_bf16_supported(const JointGeom& g) {
 int launch_joint_fwd_bf16(hipStream_t st, const float* x, const float* y, const float* mask, const JointGeom& g, const int32_t* win,
                           float* partials, int nterms) {
     const size_t ldsb = bf16_lds_bytes(g, nterms);
-    dim3 grid(g.G, g.P), block(kBT);
+    dim3 grid(g.G, g.P * g.S), block(kBT);
 #define JB(MT, NT, PAD, NTERMS)                                                                                                  \
     {                                                                                                                            \
         hipFuncSetAttribute((const void*)joint_fwd_bf16_kernel<MT, NT, PAD, NTERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \

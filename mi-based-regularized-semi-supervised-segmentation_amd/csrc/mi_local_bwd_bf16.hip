@@ -25,6 +25,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Bwd3Geom {
     int N, H, W, P, G, accumulate;
     int L;        // items (4-row tiles) per segment
+    int S;        // sub-heads in this launch: operands / outputs of head s at + s * hs elements, G and scale rows s * P + p
+    long long hs;
     int ablate;   // profiling only (MISEG_ABLATE): 1 no src tile, 2 no MFMA, 4 no col2im, 8 no output write, 16 no G streaming
 };
 
@@ -88,15 +90,18 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
     const size_t plane = (size_t)g.H * g.W;
 
     // ---- segments: (dir, window p, sample n, column strip ct, run of <= L consecutive 4-row items)
-    int64_t total = 0;
+    int64_t per_head = 0;
     for (int p = 0; p < g.P; ++p) {
         const int tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4, tc = (win[p * 4 + 3] - win[p * 4 + 2] + C::WB - 1) / C::WB;
-        total += (int64_t)g.N * tc * ((tr + g.L - 1) / g.L);
+        per_head += (int64_t)g.N * tc * ((tr + g.L - 1) / g.L);
     }
-    struct Seg { int dir, p, n, col0, h0, h1, w0, w1, rt0, rt1; };
+    const int64_t total = per_head * g.S;
+    struct Seg { int dir, s, p, n, col0, h0, h1, w0, w1, rt0, rt1; };
     auto decode = [&](int64_t sid, Seg& o) {
         o.dir = sid >= total;
         int64_t rem = sid - (o.dir ? total : 0);
+        o.s = (int)(rem / per_head);
+        rem -= (int64_t)o.s * per_head;
         int p = 0, tr = 0, tc = 0, ns = 0;
         for (; p < g.P; ++p) {
             tr = (win[p * 4 + 1] - win[p * 4 + 0] + 3) / 4;
@@ -118,10 +123,10 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
     // ---- source rows: group j = rows h0+4j .. h0+4j+3 of all K planes; wave w owns (ch,row) pairs pr = w + 8*i; ring slot (j+1) % 3
     constexpr int PFN = (K * 4) / 8;
     const unsigned tbytes = (unsigned)((size_t)g.N * K * plane * 4);
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)tbytes, 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
     auto fetch_group = [&](const Seg& o, int j, float* dst) {
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)o.s * g.hs), 0, (int)tbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)o.s * g.hs), 0, (int)tbytes, 0x00020000);
         const int col = o.col0 - PAD + lane;
         const unsigned vo = (col >= o.w0 && col < o.w1) ? (unsigned)col * 4u : OOB;
 #pragma unroll
@@ -160,11 +165,11 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
             if (idx < SLICE / 8) *reinterpret_cast<u32x4*>(Gsl + (size_t)buf * SLICE + (size_t)idx * 8) = gq[i];
         }
     };
-    auto slices_of = [&](const Seg& o) { return gpack + (size_t)(o.p * 2 + o.dir) * KS * SLICE; };
+    auto slices_of = [&](const Seg& o) { return gpack + (size_t)((o.s * g.P + o.p) * 2 + o.dir) * KS * SLICE; };
 
     // pending output of the previous item (kept in registers until the partner half's partial is visible)
     float outp[K];
-    int prow = 0, pcol0 = 0, pn = 0, pdir = 0, ph1 = 0, pw1 = 0, pp = 0;
+    int prow = 0, pcol0 = 0, pn = 0, pdir = 0, ph1 = 0, pw1 = 0, pp = 0, ps = 0;
     bool pending = false;
     auto finish_output = [&]() {
         if (!pending || half != 0) return;
@@ -175,8 +180,8 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
         }
         const int col = pcol0 + lane - PAD;
         if (prow < ph1 && lane >= PAD && lane < PAD + C::WB && col < pw1 && !((g.ablate & 8) && outp[0] != 12345.f)) {
-            const float sc = scale[pp];
-            float* op = (pdir ? gy : gx) + (size_t)pn * K * plane + (size_t)prow * g.W + col;
+            const float sc = scale[ps * g.P + pp];
+            float* op = (pdir ? gy : gx) + (size_t)ps * g.hs + (size_t)pn * K * plane + (size_t)prow * g.W + col;
             if (g.accumulate) {
                 float old[K];
 #pragma unroll
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
             };
             if (half == 0) body(std::integral_constant<int, 0>{});
             else body(std::integral_constant<int, 1>{});
-            prow = sg.h0 + 4 * rt + r4; pcol0 = sg.col0; pn = sg.n; pdir = dir; ph1 = sg.h1; pw1 = sg.w1; pp = sg.p;
+            prow = sg.h0 + 4 * rt + r4; pcol0 = sg.col0; pn = sg.n; pdir = dir; ph1 = sg.h1; pw1 = sg.w1; pp = sg.p; ps = sg.s;
             pending = true;
             base3 = base3 == 2 ? 0 : base3 + 1;
         }
@@ -359,9 +364,9 @@ static int launch_bwd3(hipStream_t st, const float* x, const float* y, Bwd3Geom 
                        const float* scale, float* gx, float* gy, void* ws, int nterms) {
     typedef B3<K, PAD> C;
     unsigned short* gpack = reinterpret_cast<unsigned short*>(ws);
-    const int total = g.P * 2 * C::KS * C::MP * 32;
-    if (nterms == 1) hipLaunchKernelGGL((pack_g_bf16_kernel<K, PAD, 1>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, g.P, gpack);
-    else hipLaunchKernelGGL((pack_g_bf16_kernel<K, PAD, 2>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, g.P, gpack);
+    const int total = g.P * g.S * 2 * C::KS * C::MP * 32;
+    if (nterms == 1) hipLaunchKernelGGL((pack_g_bf16_kernel<K, PAD, 1>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, g.P * g.S, gpack);
+    else hipLaunchKernelGGL((pack_g_bf16_kernel<K, PAD, 2>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, g.P * g.S, gpack);
     const size_t lds = bwd3_lds<K, PAD>(nterms);
     if (nterms == 1) {
         hipFuncSetAttribute((const void*)local_bwd_bf16_kernel<K, PAD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -373,16 +378,16 @@ static int launch_bwd3(hipStream_t st, const float* x, const float* y, Bwd3Geom 
     return 0;
 }
 
-int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
+int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
                           const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
                           void* ws, int nterms) {
-    Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate, 8, 0};
+    Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate, 8, (int)S, (long long)hs, 0};
     { const char* ab = getenv("MISEG_ABLATE"); g.ablate = ab ? atoi(ab) : 0; }
     if (P == 1) {   // one whole-image window (the shipped configuration): pick the segment length with the best block balance
         const int wb = 64 - 2 * (int)pad, tr = ((int)H + 3) / 4, tc = ((int)W + wb - 1) / wb;
         double best = 1e30;
         for (int L = 4; L <= 64; L *= 2) {
-            const int64_t segs = 2 * N * tc * ((tr + L - 1) / L);
+            const int64_t segs = 2 * S * N * tc * ((tr + L - 1) / L);
             const double cost = (double)((segs + g.G - 1) / g.G) * (std::min(L, tr) + 1.0);   // +1: ring warm-up per segment
             if (cost < best) { best = cost; g.L = L; }
         }

@@ -176,8 +176,15 @@ class _LocalMIHeads(torch.autograd.Function):
         p, t, dev = len(windows), 2 * pad + 1, probs.device
         win = windows_tensor(windows, dev)
         raw = torch.empty(s, p, t, t, k, k, dtype=torch.float32, device=dev)
-        for i in range(s):
-            _local_fwd(probs[i, :ub], probs[i, ub:], mask, pad, windows, win, raw[i])
+        if mask is None:    # every sub-head in one launch
+            ws = _ws(max(query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, p * s),
+                         query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, p)), dev)   # batched launch | per-head fallback
+            px = sum((a1 - a0) * (b1 - b0) for a0, a1, b0, b1 in windows)
+            call("miseg_iic_local_joint_fwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, pad, _ptr(win), p, _ptr(raw), _ptr(ws), ws.numel(),
+                 _mi_precision, work=(2.0 * k * k * t * t * ub * px * s, 2.0 * ub * k * px * 4 * s), tag=f"iic_local_joint_fwd[p{pad}]")
+        else:
+            for i in range(s):
+                _local_fwd(probs[i, :ub], probs[i, ub:], mask, pad, windows, win, raw[i])
         loss = torch.empty(s, p, dtype=torch.float32, device=dev)
         grad_raw = torch.empty_like(raw)
         call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, s * p, float(lamda), _ptr(loss), _ptr(grad_raw))
@@ -192,9 +199,24 @@ class _LocalMIHeads(torch.autograd.Function):
         ub = ctx.ub
         gprob = torch.empty_like(probs) if _is_whole(ctx.windows, h, w) else torch.zeros_like(probs)
         scale = gloss.contiguous().float()
-        for i in range(s):
-            _local_bwd(probs[i, :ub], probs[i, ub:], mask, ctx.pad, ctx.windows, win, grad_raw[i], scale[i], gprob[i, :ub],
-                       gprob[i, ub:])
+        if mask is None:
+            whole = _is_whole(ctx.windows, h, w)
+            tt = (2 * ctx.pad + 1) ** 2
+            bws = _ws(query("miseg_iic_local_bwd_ws_bytes", k, ctx.pad, len(ctx.windows) * s), probs.device)   # >= the per-head size
+            for grp in colour_windows(ctx.windows):
+                if len(grp) == len(ctx.windows):
+                    gwin, ggrad, gscale = win, grad_raw, scale
+                else:
+                    idx = cached_const(("idx", str(probs.device), tuple(grp)), lambda: torch.tensor(grp, dtype=torch.long, device=probs.device))
+                    gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[:, idx].contiguous(), scale[:, idx].contiguous()
+                px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
+                call("miseg_iic_local_bwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, ctx.pad, _ptr(gwin), len(grp), _ptr(ggrad),
+                     _ptr(gscale), _ptr(gprob), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(),
+                     work=(4.0 * k * k * tt * ub * px * s, 4.0 * ub * k * px * 4 * s), tag=f"iic_local_bwd[p{ctx.pad}]")
+        else:
+            for i in range(s):
+                _local_bwd(probs[i, :ub], probs[i, ub:], mask, ctx.pad, ctx.windows, win, grad_raw[i], scale[i], gprob[i, :ub],
+                           gprob[i, ub:])
         return gprob, None, None, None, None, None
 
 
