@@ -131,17 +131,33 @@ __device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T
     for (int i = 0; i < V; ++i) { sc[i] = saved[2 * C + cv * V + i]; sh[i] = saved[3 * C + cv * V + i]; }
     if (!POOL) {
         const int64_t npix = (int64_t)N * H * W;
-        for (int64_t px = first; px < npix; px += step) {
-            const int64_t o = px * CV + cv;
-            float fr[V], fg[V], fy[V];
-            VT<T>::unpack(reinterpret_cast<const Raw*>(raw)[o], fr);
-            VT<T>::unpack(reinterpret_cast<const Raw*>(gy)[o], fg);
+        // U pixels per trip: 2*U 16-byte loads in flight per thread (one pair per trip leaves the loop latency-bound:
+        // 16 waves x 64 lanes x 32 B = 32 KB outstanding per CU)
+        constexpr int U = 4;
+        for (int64_t px = first; px < npix; px += U * step) {
+            Raw rr[U], gg[U];
 #pragma unroll
-            for (int i = 0; i < V; ++i) fy[i] = fmaxf(fr[i] * sc[i] + sh[i], 0.f);
-            VT<T>::unpack(VT<T>::pack(fy), fy);
+            for (int u = 0; u < U; ++u) {
+                const int64_t pu = px + u * step;
+                const int64_t o = (pu < npix ? pu : px) * CV + cv;
+                rr[u] = reinterpret_cast<const Raw*>(raw)[o];
+                gg[u] = reinterpret_cast<const Raw*>(gy)[o];
+            }
 #pragma unroll
-            for (int i = 0; i < V; ++i) fg[i] = fy[i] > 0.f ? fg[i] : 0.f;
-            f(o, fr, fg);
+            for (int u = 0; u < U; ++u) {
+                const int64_t pu = px + u * step;
+                if (pu < npix) {
+                    float fr[V], fg[V], fy[V];
+                    VT<T>::unpack(rr[u], fr);
+                    VT<T>::unpack(gg[u], fg);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) fy[i] = fmaxf(fr[i] * sc[i] + sh[i], 0.f);
+                    VT<T>::unpack(VT<T>::pack(fy), fy);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) fg[i] = fy[i] > 0.f ? fg[i] : 0.f;
+                    f(pu * CV + cv, fr, fg);
+                }
+            }
         }
     } else {
         const int Hp = H / 2, Wp = W / 2;
@@ -206,17 +222,32 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
             a2[i] += dz[i] * (fr[i] - mean[i]) * invstd[i];
         }
     });
-    // block reduce over threads sharing cv (256 % CV == 0): sacc[tid][2V]
+    // block reduce over the 256/CV threads that share a channel vector (CV | 256, block start is a multiple of CV):
+    // sacc[tid][2V]; output (cvv, j) = sum over rows t = cvv (mod CV).  All 256 threads take part: 2C outputs x nparts
+    // partial sums first (the old form left this to CV threads -- 2 of 256 for a 16-channel layer), then a fixed-order
+    // combine: deterministic, independent of the grid.
 #pragma unroll
     for (int i = 0; i < V; ++i) { sacc[threadIdx.x * 2 * V + i] = a1[i]; sacc[threadIdx.x * 2 * V + V + i] = a2[i]; }
     __syncthreads();
-    if (threadIdx.x < CV) {
-        // block's first thread has gid % CV == (blockIdx.x*256) % CV == 0 since CV | 256
-        for (int i = 0; i < V; ++i) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int t = threadIdx.x; t < 256; t += CV) { s1 += sacc[t * 2 * V + i]; s2 += sacc[t * 2 * V + V + i]; }
-            parts[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x * V + i] = s1;
-            parts[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x * V + i] = s2;
+    const int nout = 2 * C, rows = 256 / CV;                 // outputs of this block; rows per output
+    const int nparts = nout >= 256 ? 1 : 256 / nout;         // threads cooperating on one output
+    __shared__ float spart[256];
+    for (int o0 = 0; o0 < nout; o0 += 256) {
+        const int o = o0 + (nparts == 1 ? (int)threadIdx.x : (int)threadIdx.x % nout), part = nparts == 1 ? 0 : (int)threadIdx.x / nout;
+        float sum = 0.f;
+        if (o < nout && part < nparts) {
+            const int cvv = o / (2 * V), j = o % (2 * V);
+            for (int m = part; m < rows; m += nparts) sum += sacc[(cvv + CV * m) * 2 * V + j];
+        }
+        if (o0) __syncthreads();
+        spart[threadIdx.x] = sum;
+        __syncthreads();
+        if ((int)threadIdx.x < nout - o0 && (int)threadIdx.x < 256 && (nparts == 1 || (int)threadIdx.x < nout)) {
+            const int oo = o0 + (int)threadIdx.x;
+            float tot = 0.f;
+            for (int q = 0; q < nparts; ++q) tot += spart[nparts == 1 ? (int)threadIdx.x : q * nout + (int)threadIdx.x];
+            const int cvv = oo / (2 * V), j = oo % (2 * V);
+            parts[((size_t)blockIdx.x * 2 + (j >= V)) * C + cvv * V + (j % V)] = tot;
         }
     }
 }
@@ -334,7 +365,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 static inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 8192)); }
-static inline int red_blocks(int64_t npix, int CV) { (void)CV; return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(npix, 64), 1024)); }
+static inline int red_blocks(int64_t npix, int CV) {
+    (void)CV;
+    static const int cap = [] { const char* e = getenv("MISEG_RED_BLOCKS"); return e ? atoi(e) : 512; }();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(npix, 64), cap));
+}
 
 }  // namespace miseg
 
