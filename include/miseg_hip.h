@@ -112,7 +112,8 @@ int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S
  * local  bwd: gprob same shape -> gfeat NHWC [B,H,W,C] (dt): rows src[m] are OVERWRITTEN with the gradient, all
  *             other rows are left as they are (callers pass a zeroed buffer); src[] must be pairwise distinct (each
  *             gfeat element then has one writer -- the epocher's src is an arange); gw [S][K][C], gb [S][K] overwritten.
- * global fwd: prob fp32 [S][M][K]; bwd likewise (flips are irrelevant under global pooling).
+ * global fwd: prob fp32 [S][M][K]; bwd likewise (flips are irrelevant under global pooling); gfeat rows src[m] are
+ *             overwritten (zeroed buffer, distinct src -- as for the local head).
  * ------------------------------------------------------------------------------------------ */
 /* simplex_violations (optional, needs K <= 32): += number of (sub-head, sample, pixel) positions whose K probabilities
  * do not sum to 1 within simplex_tol -- the consumer's `assert simplex(prob)` (ref iic_loss.py:28-29) for free. */

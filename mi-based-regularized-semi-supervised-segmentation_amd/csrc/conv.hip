@@ -697,17 +697,30 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int o = 0; o < CO; ++o) gbacc[o] = 0.f;
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        // the pixel's CI channels travel as 16-byte vectors both ways (2-byte scalar stores were the bottleneck)
+        constexpr int NV = CI * (int)sizeof(T) / 16;
+        static_assert(CI * sizeof(T) % 16 == 0, "conv1x1_bwd: the channel vector must be a multiple of 16 bytes");
+        uint4 vin[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vin[v] = reinterpret_cast<const uint4*>(in + i * CI)[v];
+        const T* fe = reinterpret_cast<const T*>(vin);
         float f[CI], g[CO];
 #pragma unroll
-        for (int c = 0; c < CI; ++c) f[c] = to_f32(in[i * CI + c]);
+        for (int c = 0; c < CI; ++c) f[c] = to_f32(fe[c]);
 #pragma unroll
         for (int o = 0; o < CO; ++o) { g[o] = gout[i * CO + o]; gbacc[o] += g[o]; }
+        uint4 vout[NV];
+        T* oe = reinterpret_cast<T*>(vout);
 #pragma unroll
         for (int c = 0; c < CI; ++c) {
             float a = 0.f;
 #pragma unroll
             for (int o = 0; o < CO; ++o) { a += w[o * CI + c] * g[o]; gwacc[o * CI + c] += g[o] * f[c]; }
-            if (gin) gin[i * CI + c] = from_f32<T>(a);
+            oe[c] = from_f32<T>(a);
+        }
+        if (gin) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) reinterpret_cast<uint4*>(gin + i * CI)[v] = vout[v];
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -112,14 +112,31 @@ __global__ __launch_bounds__(256) void iic_global_bwd_kernel(const float* __rest
 
 // ---------------------------------------------------------------- encoder ClusterHead (linear)
 // pooled[m][c] = mean_{h,w} feat[src[m]][h][w][c];  prob[s][m][:] = softmax((W_s pooled + b_s)/T)
+// grid (M, ceil(C/32)): a block owns 32 channels of one sample; its 8 thread rows split the pixels (8 interleaved streams of
+// 64-byte coalesced reads instead of one thread walking all HW pixels), combined through LDS in fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void head_pool_kernel(const T* __restrict__ feat, int HW, int C, const int32_t* __restrict__ src,
                                                         float* __restrict__ pooled) {
-    const int m = blockIdx.x;
+    __shared__ float part[8][32];
+    const int m = blockIdx.x, c = blockIdx.y * 32 + (threadIdx.x & 31), row = threadIdx.x >> 5;
     const T* f = feat + (size_t)src[m] * HW * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int p = row;
+        for (; p + 24 < HW; p += 32) {
+            s0 += to_f32(f[(size_t)p * C + c]);
+            s1 += to_f32(f[(size_t)(p + 8) * C + c]);
+            s2 += to_f32(f[(size_t)(p + 16) * C + c]);
+            s3 += to_f32(f[(size_t)(p + 24) * C + c]);
+        }
+        for (; p < HW; p += 8) s0 += to_f32(f[(size_t)p * C + c]);
+    }
+    part[row][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (row == 0 && c < C) {
         float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += to_f32(f[(size_t)p * C + c]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += part[r][threadIdx.x];
         pooled[(size_t)m * C + c] = s / (float)HW;
     }
 }
@@ -141,40 +158,50 @@ __global__ __launch_bounds__(64) void head_global_fwd_kernel(const float* __rest
     if (lane < K) prob[((size_t)s * M + m) * K + lane] = e / sum;
 }
 
-// one block per sub-head: dz = p*(g - <g,p>)/T; gw = dz^T pooled; gb = sum dz; gpooled[m][c] += W^T dz
+// grid (S, ceil(K*C/256)): dz = p*(g - <g,p>)/T of sub-head s is recomputed per block into LDS (M*K values); every thread
+// then owns one gw element (k, c) = sum_m dz[m][k] * pooled[m][c].  Block y == 0 also stores dz for the feature pass and gb.
 __global__ __launch_bounds__(256) void head_global_bwd_kernel(const float* __restrict__ pooled, int M, int C, const float* __restrict__ w,
                                                               int S, int K, float T, const float* __restrict__ prob,
                                                               const float* __restrict__ gprob, float* __restrict__ dz_all,
                                                               float* __restrict__ gw, float* __restrict__ gb) {
+    extern __shared__ float dzs[];   // [M][K]
     const int s = blockIdx.x;
-    float* dz = dz_all + (size_t)s * M * K;
     for (int m = threadIdx.x; m < M; m += blockDim.x) {
         const float* p = prob + ((size_t)s * M + m) * K;
         const float* g = gprob + ((size_t)s * M + m) * K;
         float dot = 0.f;
         for (int k = 0; k < K; ++k) dot += g[k] * p[k];
-        for (int k = 0; k < K; ++k) dz[m * K + k] = p[k] * (g[k] - dot) / T;
+        for (int k = 0; k < K; ++k) dzs[m * K + k] = p[k] * (g[k] - dot) / T;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < K * C; e += blockDim.x) {
-        int k = e / C, c = e % C;
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e < K * C) {
+        const int k = e / C, c = e % C;
         float a = 0.f;
-        for (int m = 0; m < M; ++m) a += dz[m * K + k] * pooled[(size_t)m * C + c];
+        for (int m = 0; m < M; ++m) a += dzs[m * K + k] * pooled[(size_t)m * C + c];
         gw[(size_t)s * K * C + e] = a;
     }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float a = 0.f;
-        for (int m = 0; m < M; ++m) a += dz[m * K + k];
-        gb[s * K + k] = a;
+    if (blockIdx.y == 0) {
+        float* dz = dz_all + (size_t)s * M * K;
+        for (int i = threadIdx.x; i < M * K; i += blockDim.x) dz[i] = dzs[i];
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            float a = 0.f;
+            for (int m = 0; m < M; ++m) a += dzs[m * K + k];
+            gb[s * K + k] = a;
+        }
     }
 }
 
-// gfeat[src[m]][h][w][c] += (sum_{s,k} W[s][k][c] dz[s][m][k]) / HW      (avg-pool backward; src[] distinct)
+// gfeat[src[m]][h][w][c] = (sum_{s,k} W[s][k][c] dz[s][m][k]) / HW      (avg-pool backward)
+// src[] is pairwise distinct and the caller hands in a zeroed gfeat (like the local head): every row has one writer, so
+// the rows are written with plain 16-byte stores.  grid (M, nchunk): each block recomputes the C-vector gp (S*K*C FMAs)
+// and stores its share of the HW pixels.
 template <typename T>
 __global__ __launch_bounds__(256) void head_global_bwd_feat_kernel(const float* __restrict__ dz_all, int M, int HW, int C,
                                                                    const int32_t* __restrict__ src, const float* __restrict__ w,
                                                                    int S, int K, T* __restrict__ gfeat) {
     extern __shared__ float gp[];  // [C]
+    constexpr int V = 16 / (int)sizeof(T);
     const int m = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float a = 0.f;
@@ -184,7 +211,14 @@ __global__ __launch_bounds__(256) void head_global_bwd_feat_kernel(const float* 
     }
     __syncthreads();
     T* g = gfeat + (size_t)src[m] * HW * C;
-    for (int e = threadIdx.x; e < HW * C; e += blockDim.x) g[e] = from_f32<T>(to_f32(g[e]) + gp[e % C]);
+    const int nvec = HW * C / V, cv = C / V;                 // host guarantees C % V == 0
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < nvec; e += gridDim.y * 256) {
+        T pk[V];
+        const int c0 = (e % cv) * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) pk[i] = from_f32<T>(gp[c0 + i]);
+        reinterpret_cast<uint4*>(g)[e] = *reinterpret_cast<const uint4*>(pk);
+    }
 }
 
 }  // namespace miseg
@@ -218,9 +252,9 @@ extern "C" int miseg_head_global_fwd(void* stream, int dt, const void* feat, int
     MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_fwd: bad shape (K<=64)");
     hipStream_t st = as_stream(stream);
     if (dt == MISEG_F32)
-        hipLaunchKernelGGL(head_pool_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)feat, (int)(H * W), (int)C, src, pooled);
+        hipLaunchKernelGGL(head_pool_kernel<float>, dim3((unsigned)M, (unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)feat, (int)(H * W), (int)C, src, pooled);
     else
-        hipLaunchKernelGGL(head_pool_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, (const bf16*)feat, (int)(H * W), (int)C, src, pooled);
+        hipLaunchKernelGGL(head_pool_kernel<bf16>, dim3((unsigned)M, (unsigned)cdiv(C, 32)), dim3(256), 0, st, (const bf16*)feat, (int)(H * W), (int)C, src, pooled);
     MISEG_LAUNCH_CHECK("head_pool_kernel");
     hipLaunchKernelGGL(head_global_fwd_kernel, dim3((unsigned)M, (unsigned)S), dim3(64), 0, st, pooled, (int)M, (int)C, w, b, (int)K, T, prob);
     MISEG_LAUNCH_CHECK("head_global_fwd_kernel");
@@ -234,15 +268,18 @@ extern "C" int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H,
     MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_bwd: bad shape");
     hipStream_t st = as_stream(stream);
     float* dz = dz_ws;
-    hipLaunchKernelGGL(head_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, st, pooled, (int)M, (int)C, w, (int)S, (int)K, T, prob,
+    MISEG_REQUIRE(M * K * 4 <= 64 * 1024, "head_global_bwd: M*K too large for the LDS copy of dz");
+    hipLaunchKernelGGL(head_global_bwd_kernel, dim3((unsigned)S, (unsigned)cdiv(K * C, 256)), dim3(256), (size_t)(M * K * 4), st, pooled, (int)M, (int)C, w, (int)S, (int)K, T, prob,
                        gprob, dz, gw, gb);
     MISEG_LAUNCH_CHECK("head_global_bwd_kernel");
     if (gfeat) {
+        MISEG_REQUIRE(C % (dt == MISEG_BF16 ? 8 : 4) == 0, "head_global_bwd: C must be a multiple of the 16-byte vector");
+        const unsigned fchunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(16, cdiv(H * W * C / (dt == MISEG_BF16 ? 8 : 4), 256)));
         if (dt == MISEG_F32)
-            hipLaunchKernelGGL(head_global_bwd_feat_kernel<float>, dim3((unsigned)M), dim3(256), (size_t)C * 4, st, dz, (int)M,
+            hipLaunchKernelGGL(head_global_bwd_feat_kernel<float>, dim3((unsigned)M, fchunks), dim3(256), (size_t)C * 4, st, dz, (int)M,
                                (int)(H * W), (int)C, src, w, (int)S, (int)K, (float*)gfeat);
         else
-            hipLaunchKernelGGL(head_global_bwd_feat_kernel<bf16>, dim3((unsigned)M), dim3(256), (size_t)C * 4, st, dz, (int)M,
+            hipLaunchKernelGGL(head_global_bwd_feat_kernel<bf16>, dim3((unsigned)M, fchunks), dim3(256), (size_t)C * 4, st, dz, (int)M,
                                (int)(H * W), (int)C, src, w, (int)S, (int)K, (bf16*)gfeat);
         MISEG_LAUNCH_CHECK("head_global_bwd_feat_kernel");
     }
