@@ -93,8 +93,9 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 // 64 outputs x 4 split-groups per 256-thread block; each group sums q = g, g+4, ... serially, the 4 group
 // sums are added in fixed order -> bitwise reproducible, 4x the memory-level parallelism of one thread per output.
 // reduce_partials_block: outputs per block depend on the number of parts (host side: reduce_grid)
-constexpr int kWideReduceParts = 64;
+constexpr int kWideReduceParts = 64, kFlatReduceParts = 16;
 static inline unsigned reduce_grid(int64_t total, int64_t nparts) {
+    if (nparts <= kFlatReduceParts) return (unsigned)((total + 255) / 256);
     return (unsigned)((total + (nparts >= kWideReduceParts ? 15 : 63)) / (nparts >= kWideReduceParts ? 16 : 64));
 }
 
@@ -102,6 +103,21 @@ template <typename MapFn>
 __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
                                                       float* __restrict__ out, MapFn map) {
     __shared__ float rp_sm[16][64];
+    if (nparts <= kFlatReduceParts) {
+        // few parts, many outputs: one thread per output, the parts summed in order from registers (no LDS, no barrier)
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        if (e < total) {
+            const float* p = parts + map(e);
+            float v[kFlatReduceParts];
+#pragma unroll
+            for (int q = 0; q < kFlatReduceParts; ++q) v[q] = q < nparts ? p[(size_t)q * stride] : 0.f;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < kFlatReduceParts; ++q) s += v[q];
+            out[e] = s;
+        }
+        return;
+    }
     if (nparts >= kWideReduceParts) {
         // many parts, (usually) few outputs: 16 outputs x 16 part-groups per block, 4 independent chains per thread,
         // then a fixed-order tree over the groups -- same result for any grid, ~16x the loads in flight of the narrow form

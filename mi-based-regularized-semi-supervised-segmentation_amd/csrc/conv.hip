@@ -845,7 +845,8 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
 static int wgrad_splits(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
     const int64_t ntiles = N * cdiv(H, WG_TH) * cdiv(W, WG_TW);
     const int64_t per = cdiv(Cin, 32) * cdiv(Cout, 32);
-    int64_t s = std::max<int64_t>(1, 512 / per);
+    static const int target = [] { const char* e = getenv("MISEG_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    int64_t s = std::max<int64_t>(1, target / per);
     return (int)std::min<int64_t>(s, ntiles);
 }
 
