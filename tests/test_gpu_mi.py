@@ -294,3 +294,30 @@ def test_local_head_counts_simplex_violations_for_free():
     bad2 = ops().local_head(feat, w, b, src, None, 1.0)
     bad2[0, 0, 0, 0, 0] += 0.5          # in-place edit bumps the version: the cached counter no longer applies
     assert int(checks.simplex_violations(bad2, 2)) == 1
+
+
+@pytest.mark.parametrize("pad,h,w,patch", [(3, 64, 64, 32), (1, 48, 80, 32)])
+def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch):
+    """K=20 (the shipped cluster count) puts `forward_heads` on the batched bf16 kernels: S sub-heads x P overlapping
+    patch windows in one launch forward, one launch per colour group backward (accumulating).  Compared with the exact-fp32
+    kernels run one sub-head at a time (themselves pinned to the golden vectors above): loss to 5e-7 absolute; gradients
+    to 2e-4 of the gradient scale -- each side is held to 1e-4 against the fp64 oracle elsewhere in this file, and here
+    two fp32-class evaluations are compared with each other."""
+    from contrastyou.losses.iic_loss import IIDSegmentationSmallPathLoss
+    s, ub, k = 3, 2, 20
+    crit = IIDSegmentationSmallPathLoss(padding=pad, patch_size=patch)
+    base = T(synth.probs(f"bf16heads_p{pad}_h{h}_w{w}", (s * 2 * ub, k, h, w))).view(s, 2 * ub, k, h, w).to(DEV)
+    wts = torch.arange(1, s + 1, device=DEV, dtype=torch.float32)
+    try:
+        ops().set_mi_precision("bf16x3")
+        a = base.clone().requires_grad_(True)
+        fused = crit.forward_heads(a, ub)
+        (fused * wts).sum().backward()
+    finally:
+        ops().set_mi_precision("fp32")
+    b = base.clone().requires_grad_(True)
+    loop = torch.stack([crit(q[:ub], q[ub:]) for q in b])
+    (loop * wts).sum().backward()
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), loop.detach().cpu().numpy(), rtol=0, atol=5e-7)
+    gscale = float(b.grad.abs().max())
+    np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=0, atol=2e-4 * gscale)
