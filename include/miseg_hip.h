@@ -152,7 +152,8 @@ int miseg_softmax_mse(void* stream, const float* a, const float* b, const int32_
                       int64_t W, int64_t C, const float* upstream, float* loss, float* ga, void* ws,
                       int64_t ws_bytes);
 /* per-sample H/W flip of an [N,C,H,W]-indexed tensor with arbitrary element strides (in elements),
- * elem_bytes in {2,4,8}; ref whl:deepclustering2/augment/tensor_augment.py:31-39. Bit-exact. */
+ * elem_bytes in {2,4,8}; ref whl:deepclustering2/augment/tensor_augment.py:31-39. Bit-exact.
+ * in_strides4 / out_strides4 are HOST arrays of 4 strides (read at launch time); in, out and flips are device pointers. */
 int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
                const int64_t* in_strides4, const int64_t* out_strides4, int elem_bytes, const int32_t* flips);
 /* argmax over channels + per-sample per-class intersection/union counts (int64 [N][C] each);
