@@ -660,6 +660,109 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
     for (int e = tid; e < 32 * 288; e += kCT) outp[e] = Ds[e];
 }
 
+// Narrow-layer variant (the 256^2 / 128^2 layers that are HBM-bound): a block owns 16 output channels (grid.z) x one
+// 16-channel slice of the input (grid.y), v_mfma_f32_16x16x32_bf16 (k = the 32 pixels of a tile row), 36 accumulator
+// registers instead of 144 and 19 KB of LDS instead of 38 -> ~5 blocks per CU keep enough loads in flight to stream.
+// Writes the same partial layout as conv3x3_wgrad_bf16_kernel (its 16 x 9 x 16 corner of the 32 x 288 tile).
+__global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ gout,
+                                                                       int Cout, int nsplit, float* __restrict__ partials) {
+    constexpr int IW = WG_TW + 2, NPX = WG_TH * WG_TW, NIPX = (WG_TH + 2) * IW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
+    short* Gs = reinterpret_cast<short*>(wsm_raw);            // [NPX][16]
+    short* Is = Gs + NPX * 16;                                // [NIPX][16]
+    const int Cin = src.C0 + src.C1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int g8 = 8 * kq, q = (lane >> 2) & 3, p4 = lane & 3;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16;
+    const int tilesC = (W + WG_TW - 1) / WG_TW, tilesR = (H + WG_TH - 1) / WG_TH;
+    const int ntiles = N * tilesR * tilesC;
+    f32x4 acc[9];
+#pragma unroll
+    for (int b = 0; b < 9; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    constexpr int NG = NPX * 2 / kCT, NI = (NIPX * 2 + kCT - 1) / kCT;
+    uint4 pg[NG], pi[NI];
+    auto fetch = [&](int tile) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, ix = px % WG_TW, iy = px / WG_TW;
+            const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
+            uint4 val = zero4;
+            if (h < H && w < W && c < Cout) val = *reinterpret_cast<const uint4*>(gout + (((size_t)n * H + h) * W + w) * Cout + c);
+            pg[j] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, ix = px % IW, iy = px / IW;
+            const int h = h0 - 1 + iy, w = w0 - 1 + ix, cc = ci0 + v * 8;
+            uint4 val = zero4;
+            if (idx < NIPX * 2 && h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
+                const bf16* sp;
+                if (cc < src.C0) {
+                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                    sp = reinterpret_cast<const bf16*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + cc;
+                } else {
+                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                    sp = reinterpret_cast<const bf16*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + cc - src.C0;
+                }
+                val = *reinterpret_cast<const uint4*>(sp);
+            }
+            pi[j] = val;
+        }
+    };
+    if (split < ntiles) fetch(split);
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + kCT * j;
+            *reinterpret_cast<uint4*>(Gs + (idx >> 1) * 16 + (idx & 1) * 8) = pg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + kCT * j;
+            if (idx < NIPX * 2) *reinterpret_cast<uint4*>(Is + (idx >> 1) * 16 + (idx & 1) * 8) = pi[j];
+        }
+        __syncthreads();
+        if (tile + nsplit < ntiles) fetch(tile + nsplit);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wv * 2 + rr;
+            const bf16x8_t a0 = tr_frag(Gs + (row * WG_TW + g8) * 16, q, p4);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const bf16x8_t b0 = tr_frag(Is + ((row + ky) * IW + g8 + kx) * 16, q, p4);
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // reduce the 4 waves in LDS (fixed order): D[row = co = kq*4 + r][col = ci = l15] -> Ds[co][tap*16 + ci]
+    float* Ds = reinterpret_cast<float*>(wsm_raw);   // 16 x 144 floats = 9.2 KB
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (kq * 4 + r) * 144 + tap * 16 + l15;
+                    if (w == 0) Ds[o] = acc[tap][r];
+                    else Ds[o] += acc[tap][r];
+                }
+        }
+    }
+    __syncthreads();
+    const int nci32 = (Cin + 31) / 32, nco32 = (Cout + 31) / 32;
+    float* outp = partials + (((size_t)split * nco32 + blockIdx.z / 2) * nci32 + blockIdx.y / 2) * (32 * 288) + (blockIdx.y & 1) * 16;
+    for (int e = tid; e < 16 * 144; e += kCT) {
+        const int co = (blockIdx.z & 1) * 16 + e / 144, tap = (e % 144) / 16, ci = e % 16;
+        outp[co * 288 + tap * 32 + ci] = Ds[e];
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int Cout, int Cin, int nco,
                                                            int nci, float* __restrict__ gw) {
     const size_t stride = (size_t)nco * nci * (32 * 288);
@@ -871,8 +974,18 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
     } else if (dt == MISEG_BF16) {
         MISEG_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "conv3x3_wgrad: bf16 needs channel counts that are multiples of 8");
         const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2, (size_t)32 * 288 * 4);
+        // narrow layers (measured per shape, scratch/time_conv.py): the lean 16x16-tile kernel wins when one side has <= 16
+        // channels (256^2 16->16: 125 -> 52 us, 32->16: 129 -> 83, 128^2 16->32: 85 -> 48) and for 32->64 (71 -> 53);
+        // from 32->32 up the 32x32-tile kernel's operand reuse wins
+        const bool narrow = Cout % 16 == 0 && (std::min(Cin, Cout) <= 16 || (Cin == 32 && Cout == 64));
+        if ((narrow || Cout <= 16) && !getenv("MISEG_WGRAD_NO_C16")) {
+            const size_t lbc = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * 16 * 2;
+            dim3 gridc(ns, (unsigned)cdiv(Cin, 16), (unsigned)cdiv(Cout, 16));
+            hipLaunchKernelGGL(conv3x3_wgrad_bf16_c16_kernel, gridc, dim3(kCT), lbc, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
+        } else {
         hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbb);
         hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, grid, dim3(kCT), lbb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
+        }
     } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
     MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     const int total = (int)(Cout * Cin * 9);
