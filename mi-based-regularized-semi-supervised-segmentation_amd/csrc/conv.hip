@@ -55,22 +55,22 @@ __device__ __forceinline__ void zero_vec(T* dst) {
 }
 
 // COT: output channels per block; TW: tile width (32 or 16).  grid = (N*tilesR*tilesC, ceil(Cout/COT)).
-template <typename T, int COT, int TW>
+template <typename T, int COT, int TW, int THT>
 __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
                                                         T* __restrict__ out, float* __restrict__ stats) {
     typedef Mma<T> MM;
-    constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
+    constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, RW = THT / 4, MTW = RW * MTR;   // RW rows of the tile per wave
     constexpr int KP = MM::KP;                              // LDS stride of one pixel / one weight row (elements)
-    constexpr int IW = TW + 2, IH = TH + 2;
+    constexpr int IW = TW + 2, IH = THT + 2;
     constexpr int NIS = (IH * IW * (CK / VEC) + kCT - 1) / kCT, NWS = (9 * COT * (CK / VEC) + kCT - 1) / kCT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][KP]
     T* Ws = Is + IH * IW * KP;                             // [9][COT][KP]
     const int Cin = src.C0 + src.C1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int tilesC = (W + TW - 1) / TW, tilesR = (H + TH - 1) / TH;
+    const int tilesC = (W + TW - 1) / TW, tilesR = (H + THT - 1) / THT;
     const int tc = blockIdx.x % tilesC, tr = (blockIdx.x / tilesC) % tilesR, n = blockIdx.x / (tilesC * tilesR);
-    const int h0 = tr * TH, w0 = tc * TW, co0 = blockIdx.y * COT;
+    const int h0 = tr * THT, w0 = tc * TW, co0 = blockIdx.y * COT;
 
     f32x4 acc[MTW][NT];
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
         }
     };
     // every fragment read below is one of these two bases plus a compile-time offset (an instruction immediate)
-    const T* Ib = Is + ((wv * 4) * IW + l15) * KP;
+    const T* Ib = Is + ((wv * RW) * IW + l15) * KP;
     const T* Wb = Ws + l15 * KP;
     fetch(0);
     for (int c0 = 0; c0 < Cin; c0 += CK) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
         for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
-        const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+        const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
         const bool ok = h < H && w < W;
         T* op = out + (((size_t)n * H + h) * W + w) * Cout;
 #pragma unroll
@@ -886,10 +886,19 @@ static bool conv_streams(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
 }
 static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) { return std::min<int64_t>(N * cdiv(H, TH) * cdiv(W, 32), 512); }
 
+// tile height of the generic kernel (bf16): 8 rows from 64^2 upwards (smaller LDS tile -> two blocks per CU; measured
+// 128^2 64->32: 78 -> 64 us), 16 rows for the small deep layers (32^2: 8-row tiles cost 46 -> 55 us) and for exact fp32
+static int generic_tile_h(int dt, int64_t H, int64_t W) {
+    static const int force = [] { const char* e = getenv("MISEG_CONV_TH"); return e ? atoi(e) : 0; }();
+    if (dt != MISEG_BF16) return 16;
+    if (force == 8 || force == 16) return force;
+    return H * W >= 64 * 64 ? 8 : 16;
+}
+
 extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
     if (conv_streams(dt, Cin, N, H, W)) return stream_blocks(N, H, W);
     const int tw = tile_w(W);
-    return N * cdiv(H, TH) * cdiv(W, tw);
+    return N * cdiv(H, generic_tile_h(dt, H, W)) * cdiv(W, tw);
 }
 
 extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
@@ -903,15 +912,17 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
     MISEG_REQUIRE(C0 % vec == 0 && C1 % vec == 0, "conv3x3_fwd: channel counts must be multiples of %d (use conv_small for the stem)", vec);
     ConvSrc s{in0, in1, (int)C0, (int)C1, ups0, ups1};
     const int tw = tile_w(W);
-    const unsigned gx = (unsigned)(N * cdiv(H, TH) * cdiv(W, tw));
+    const int th = conv_streams(dt, C0 + C1, N, H, W) ? TH : generic_tile_h(dt, H, W);
+    const unsigned gx = (unsigned)(N * cdiv(H, th) * cdiv(W, tw));
     hipStream_t st = as_stream(stream);
-#define LAUNCH(TT, COT, TWW)                                                                                              \
+#define LAUNCH_TH(TT, COT, TWW, THH)                                                                                       \
     {                                                                                                                     \
-        size_t lb = ((size_t)(TH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);                                   \
-        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
+        size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);                                  \
+        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
                            (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats);                                       \
     }
+#define LAUNCH(TT, COT, TWW) { if (th == 8) LAUNCH_TH(TT, COT, TWW, 8) else LAUNCH_TH(TT, COT, TWW, 16) }
     if (conv_streams(dt, C0 + C1, N, H, W)) {
 #define SLAUNCH(COT, NV, DU)                                                                                               \
     {                                                                                                                     \
@@ -941,6 +952,7 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
         else { if (tw == 32) LAUNCH(float, 32, 32) else LAUNCH(float, 32, 16) }
     } else return fail(MISEG_E_INVALID, "conv3x3_fwd: bad dtype");
 #undef LAUNCH
+#undef LAUNCH_TH
     MISEG_LAUNCH_CHECK("conv3x3_kernel");
     return MISEG_OK;
 }
