@@ -313,7 +313,26 @@ class IICTrainEpocher(TrainEpocher):
         assert IIDSegCriterionWrapper.feature_names == self._feature_position
         self._IIDSegCriterionWrapper = IIDSegCriterionWrapper
 
-    def _iic(self, flips: Tensor, ub: int) -> Tensor:
+    def _iic(self, flips: Tensor, ub: int):
+        """The IIC branch runs on its own HIP stream: autograd replays backward nodes on the stream of their forward op, so
+        the matrix-core-bound local-MI backward of the Up_conv3 tap (and the global heads) overlap the HBM-bound
+        BatchNorm / weight-gradient kernels of the Up_conv2 / Up2 blocks on the main stream.  Forward order below (Conv5,
+        Up_conv3, Up_conv2) makes the backward run the Up_conv2 chain first -- the one the main stream waits for."""
+        if not flips.is_cuda or os.environ.get("MISEG_IIC_STREAM", "1") != "1" or torch.cuda.is_current_stream_capturing():
+            return self._iic_body(flips, ub)
+        main = torch.cuda.current_stream(flips.device)
+        side = getattr(self, "_iic_stream", None)
+        if side is None:
+            side = self._iic_stream = torch.cuda.Stream(device=flips.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = self._iic_body(flips, ub)
+        main.wait_stream(side)
+        for t, _ in LinearLoss.of(out).terms:      # produced on `side`, read on `main`: keep the allocator informed
+            t.record_stream(main)
+        return out
+
+    def _iic_body(self, flips: Tensor, ub: int):
         dev = flips.device
         flips2 = self._flips2 if getattr(self, "_flips2", None) is not None and len(self._flips2) == 2 * ub \
             else torch.cat([flips, torch.zeros_like(flips)])
