@@ -49,20 +49,27 @@ class FeatureExtractor(nn.Module):
     class _Tap:
         feature = None
 
+        def __init__(self, owner=None, name=None):
+            self._owner, self._name = owner, name
+
         def __call__(self, _module, _inputs, result):
             self.feature = result
+            cb = getattr(self._owner, "on_feature", None)   # optional: consumers that want the tap the moment it exists
+            if cb is not None:
+                cb(self._name, result)
 
     def __init__(self, net: UNet, feature_names: Union[List[str], str]) -> None:
         super().__init__()
         self._net = net
         self._feature_names = [feature_names] if isinstance(feature_names, str) else feature_names
+        self.on_feature = None
         for f in self._feature_names:
             assert f in _ENCODER + _DECODER, f
 
     def __enter__(self):
         self._feature_exactors, self._hook_handlers = {}, {}
         for f in self._feature_names:
-            tap = self._Tap()
+            tap = self._Tap(self, f)
             self._hook_handlers[f] = getattr(self._net, f).register_forward_hook(tap)
             self._feature_exactors[f] = tap
         return self

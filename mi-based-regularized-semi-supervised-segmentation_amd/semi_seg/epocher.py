@@ -184,6 +184,12 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             inter, union = self._device_step(labeled_image, labeled_target, unlabeled_image, flips2, seed)
         return inter, union, label_group
 
+    def _before_forward(self, ub: int) -> None:   # hooks for epochers that start work while the network is still running
+        pass
+
+    def _after_forward(self) -> None:
+        pass
+
     def enable_step_graph(self, warmup: int = 3) -> None:
         """Replay the device half of the iteration as one hipGraph (miseg_amd.graph.StepGraph): the ~560 launches of a
         step then cost the host one call.  Single-GPU only; data-parallel runs (a GradReducer is attached) stay eager."""
@@ -199,10 +205,15 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         unlabeled_image_tf = ops.flip(unlabeled_image, flips)
         assert unlabeled_image_tf.shape == unlabeled_image.shape
 
-        predict_logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
+        with checks.deferred(self._pending.checks):   # simplex / NaN assertions are raised at this iteration's fetch()
+            self._before_forward(ub)
+            try:
+                predict_logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
+            finally:
+                self._after_forward()
         label_logits, unlabel_logits, unlabel_tf_logits = torch.split(predict_logits, [lb, ub, ub], dim=0)
         labels = labeled_target.squeeze(1)
-        with checks.deferred(self._pending.checks):   # simplex / NaN assertions are raised at this iteration's fetch()
+        with checks.deferred(self._pending.checks):
             if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
                 sup_loss = self._sup_criterion.from_logits(label_logits, labels)
             else:
@@ -313,17 +324,45 @@ class IICTrainEpocher(TrainEpocher):
         assert IIDSegCriterionWrapper.feature_names == self._feature_position
         self._IIDSegCriterionWrapper = IIDSegCriterionWrapper
 
-    def _iic(self, flips: Tensor, ub: int):
-        """The IIC branch runs on its own HIP stream: autograd replays backward nodes on the stream of their forward op, so
-        the matrix-core-bound local-MI backward of the Up_conv3 tap (and the global heads) overlap the HBM-bound
-        BatchNorm / weight-gradient kernels of the Up_conv2 / Up2 blocks on the main stream.  Forward order below (Conv5,
-        Up_conv3, Up_conv2) makes the backward run the Up_conv2 chain first -- the one the main stream waits for."""
-        if not flips.is_cuda or os.environ.get("MISEG_IIC_STREAM", "1") != "1" or torch.cuda.is_current_stream_capturing():
-            return self._iic_body(flips, ub)
-        main = torch.cuda.current_stream(flips.device)
+    # ---- The IIC branch runs on its own HIP stream.  (1) Each tapped feature is turned into its MI loss the moment the
+    # forward hook delivers it (FeatureExtractor.on_feature), so heads + joint of the Up_conv3 tap overlap the rest of the
+    # decoder on the main stream; (2) autograd replays backward nodes on the stream of their forward op, so the
+    # matrix-core-bound local-MI backward of the earlier taps overlaps the HBM-bound BatchNorm / weight-gradient kernels of
+    # the later decoder blocks.  Backward runs the most recently created chain first, i.e. the last tap -- the one the main
+    # stream has to wait for -- goes first.
+    def _use_side_stream(self, dev) -> bool:
+        return dev.type == "cuda" and os.environ.get("MISEG_IIC_STREAM", "1") == "1" and not torch.cuda.is_current_stream_capturing()
+
+    def _side(self, dev):
         side = getattr(self, "_iic_stream", None)
         if side is None:
-            side = self._iic_stream = torch.cuda.Stream(device=flips.device)
+            side = self._iic_stream = torch.cuda.Stream(device=dev)
+        return side
+
+    def _before_forward(self, ub: int) -> None:
+        self._early, self._ub_now = {}, ub
+        fx = getattr(self, "_fextractor", None)
+        if fx is not None and hasattr(fx, "on_feature") and self._use_side_stream(self._flips2.device):
+            fx.on_feature = self._on_feature
+
+    def _after_forward(self) -> None:
+        fx = getattr(self, "_fextractor", None)
+        if fx is not None and hasattr(fx, "on_feature"):
+            fx.on_feature = None
+
+    def _on_feature(self, name: str, feature: Tensor) -> None:
+        idx = self._feature_position.index(name)
+        projector, criterion = list(self._projectors_wrapper)[idx], list(self._IIDSegCriterionWrapper)[idx]
+        main, side = torch.cuda.current_stream(feature.device), self._side(feature.device)
+        side.wait_stream(main)
+        feature.record_stream(side)
+        with torch.cuda.stream(side):
+            self._early[name] = self._tap_loss(feature, projector, criterion, self._flips2, self._ub_now)
+
+    def _iic(self, flips: Tensor, ub: int):
+        if not self._use_side_stream(flips.device):
+            return self._iic_body(flips, ub)
+        main, side = torch.cuda.current_stream(flips.device), self._side(flips.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             out = self._iic_body(flips, ub)
@@ -332,28 +371,32 @@ class IICTrainEpocher(TrainEpocher):
             t.record_stream(main)
         return out
 
+    def _tap_loss(self, feature: Tensor, projector, criterion, flips2: Tensor, ub: int):
+        total = feature.shape[0]
+        # last 2*UB samples of the tap: [features(unlabeled) | features(flip(unlabeled))]   (ref :258-259)
+        src = ops.arange_i32(total - 2 * ub, total, feature.device)
+        if isinstance(projector, ClusterHead):  # encoder tap: global pooling is flip-invariant (ref :261-262)
+            probs = projector.forward_gathered(feature, src)                       # [S, 2UB, K]
+            if _DEBUG_ASSERTS:
+                from contrastyou.losses.iic_loss import simplex
+                assert simplex(probs.flatten(0, 1))
+            per_head, _, _ = ops.global_mi(probs[:, :ub], probs[:, ub:], criterion.lamb)
+            return LinearLoss.mean(per_head)
+        # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
+        probs = projector.forward_gathered(feature, src, flips2)  # [S, 2UB, K, H, W]
+        if hasattr(criterion, "forward_heads"):   # all sub-heads as one autograd node (gradient lands in one buffer)
+            return criterion.forward_heads(probs, ub, lazy=True)
+        return average_iter([criterion(p[:ub], p[ub:]) for p in probs])
+
     def _iic_body(self, flips: Tensor, ub: int):
-        dev = flips.device
         flips2 = self._flips2 if getattr(self, "_flips2", None) is not None and len(self._flips2) == 2 * ub \
             else torch.cat([flips, torch.zeros_like(flips)])
+        early = getattr(self, "_early", {})
         losses = []
-        for feature, projector, criterion in zip(self._fextractor, self._projectors_wrapper, self._IIDSegCriterionWrapper):
-            total = feature.shape[0]
-            # last 2*UB samples of the tap: [features(unlabeled) | features(flip(unlabeled))]   (ref :258-259)
-            src = ops.arange_i32(total - 2 * ub, total, dev)
-            if isinstance(projector, ClusterHead):  # encoder tap: global pooling is flip-invariant (ref :261-262)
-                probs = projector.forward_gathered(feature, src)                       # [S, 2UB, K]
-                if _DEBUG_ASSERTS:
-                    from contrastyou.losses.iic_loss import simplex
-                    assert simplex(probs.flatten(0, 1))
-                per_head, _, _ = ops.global_mi(probs[:, :ub], probs[:, ub:], criterion.lamb)
-                losses.append(LinearLoss.mean(per_head))
-            else:  # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
-                probs = projector.forward_gathered(feature, src, flips2)  # [S, 2UB, K, H, W]
-                if hasattr(criterion, "forward_heads"):   # all sub-heads as one autograd node (gradient lands in one buffer)
-                    losses.append(criterion.forward_heads(probs, ub, lazy=True))
-                else:
-                    losses.append(average_iter([criterion(p[:ub], p[ub:]) for p in probs]))
+        for name, feature, projector, criterion in zip(self._feature_position, self._fextractor, self._projectors_wrapper,
+                                                       self._IIDSegCriterionWrapper):
+            loss = early.pop(name, None)      # already launched from the forward hook (side stream)
+            losses.append(loss if loss is not None else self._tap_loss(feature, projector, criterion, flips2, ub))
         reg_loss = weighted_average_iter(losses, self._feature_importance)
         self._pending.put("mi", -reg_loss)
         for name, v in zip(self._feature_position, losses):
