@@ -69,6 +69,7 @@ class GradReducer:
             for i in range(lo, hi):
                 self._bucket_of[i] = b
         self._pending: List[int] = []
+        self.producer_streams: list = []   # extra streams that write gradients (see semi_seg.epocher IIC side stream)
         self._handles: List[Optional[object]] = []
         self._armed = False
         for i, p in enumerate(flat.params):
@@ -88,6 +89,13 @@ class GradReducer:
 
     def _launch(self, b: int) -> None:
         lo, hi, start, end = self.buckets[b]
+        if self.producer_streams and self.flat.flat_grad.is_cuda:
+            # a bucket mixes gradients written on different HIP streams (the IIC branch has its own): the stream that
+            # launches the collective must see all of them
+            cur = torch.cuda.current_stream(self.flat.flat_grad.device)
+            for s in self.producer_streams:
+                if s != cur:
+                    cur.wait_stream(s)
         self.flat.collect(lo, hi)   # gradients that autograd parked elsewhere (or that never arrived) -> flat slice
         view = self.flat.flat_grad[start:end]
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM

@@ -337,6 +337,10 @@ class IICTrainEpocher(TrainEpocher):
         side = getattr(self, "_iic_stream", None)
         if side is None:
             side = self._iic_stream = torch.cuda.Stream(device=dev)
+        red = getattr(self, "_reducer", None)
+        if red is not None and side not in red.producer_streams:
+            red.producer_streams.append(side)
+            red.producer_streams.append(torch.cuda.current_stream(dev))
         return side
 
     def _before_forward(self, ub: int) -> None:
