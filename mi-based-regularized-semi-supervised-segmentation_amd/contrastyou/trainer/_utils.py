@@ -17,6 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from miseg_amd import ops
+from miseg_amd.gradslot import register_adjacent, stacked_param
 
 
 class Flatten(nn.Module):
@@ -50,9 +51,11 @@ class ClusterHead(nn.Module):
         self._headers = nn.ModuleList([
             nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), Flatten(), nn.Linear(input_dim, num_clusters), Identical(),
                           SoftmaxWithT(1, T=T)) for _ in range(num_subheads)])
+        register_adjacent([h[2].weight for h in self._headers])   # flat buffers keep the S sub-heads back to back
+        register_adjacent([h[2].bias for h in self._headers])
 
     def _wb(self):
-        return (torch.stack([h[2].weight for h in self._headers]), torch.stack([h[2].bias for h in self._headers]))
+        return stacked_param([h[2].weight for h in self._headers]), stacked_param([h[2].bias for h in self._headers])
 
     def forward_gathered(self, features: Tensor, src: Tensor) -> Tensor:
         w, b = self._wb()
@@ -72,10 +75,15 @@ class LocalClusterHead(nn.Module):
         self._headers = nn.ModuleList([
             nn.Sequential(nn.Conv2d(input_dim, num_clusters, 1, 1, 0), Identical(), SoftmaxWithT(1, T=T))
             for _ in range(num_subheads)])
+        register_adjacent([h[0].weight for h in self._headers])
+        register_adjacent([h[0].bias for h in self._headers])
 
     def _wb(self):
-        w = torch.stack([h[0].weight.view(h[0].weight.shape[0], -1) for h in self._headers])
-        return w, torch.stack([h[0].bias for h in self._headers])
+        w = stacked_param([h[0].weight for h in self._headers])          # [S, K, C, 1, 1]
+        wv = w.view(w.shape[0], w.shape[1], -1)
+        if hasattr(w, "_miseg_stack_params"):
+            wv._miseg_stack_params = w._miseg_stack_params
+        return wv, stacked_param([h[0].bias for h in self._headers])
 
     def forward_gathered(self, features: Tensor, src: Tensor, flips: Optional[Tensor]) -> Tensor:
         w, b = self._wb()

@@ -46,6 +46,7 @@ class FlatBuffers:
     def build(self) -> None:
         dev = self.params[0].device  # any device: the reducer's bucketing is also exercised on CPU/gloo in the tests;
         # the fused Adam kernel itself is GPU-only and raises on CPU tensors
+        self.params = self._layout_order(self.params)   # adjacency groups (cluster-head sub-heads) back to back
         self.offsets, off = [], 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
@@ -68,8 +69,31 @@ class FlatBuffers:
                 p._miseg_grad_slot = gview
                 p._miseg_grad_claimed = True   # slots open at zero_grad()
                 self.slots.append(gview)
+        self._offset_by_id = {id(p): o for p, o in zip(self.params, self.offsets)}
         self.flat_param, self.flat_grad = flat_p, flat_g
         unet_ops.PACK_CACHE.invalidate()
+
+    @staticmethod
+    def _layout_order(params):
+        from .gradslot import adjacent_groups
+        mine = {id(p) for p in params}
+        group_of = {}
+        for grp in adjacent_groups():
+            if all(id(p) in mine for p in grp) and all(p.numel() % 4 == 0 for p in grp):
+                for p in grp:
+                    group_of.setdefault(id(p), grp)
+        out, seen = [], set()
+        for p in params:
+            if id(p) in seen:
+                continue
+            for q in group_of.get(id(p), [p]):
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    out.append(q)
+        return out
+
+    def offset_of(self, p) -> int:
+        return self._offset_by_id[id(p)]
 
     def ensure(self) -> None:
         if not self.valid():
@@ -183,9 +207,9 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             fb = self._flats[gi]
             ids = []
-            for pi, p in enumerate(fb.params):
+            for p in group["params"]:            # torch convention: ids follow the optimiser's parameter order
                 if self._m[gi] is not None and fb.offsets:
-                    o = fb.offsets[pi]
+                    o = fb.offset_of(p)
                     state[idx] = {"step": torch.tensor(float(self._steps[gi])),
                                   "exp_avg": self._m[gi][o:o + p.numel()].view_as(p).clone(),
                                   "exp_avg_sq": self._v[gi][o:o + p.numel()].view_as(p).clone()}
@@ -196,12 +220,12 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _apply_state(self, sd: dict) -> None:
         idx = 0
-        for gi in range(len(self.param_groups)):
+        for gi, group in enumerate(self.param_groups):
             fb = self._flats[gi]
-            for pi, p in enumerate(fb.params):
+            for p in group["params"]:
                 st = sd["state"].get(idx, sd["state"].get(str(idx)))
                 if st is not None:
-                    o = fb.offsets[pi]
+                    o = fb.offset_of(p)
                     self._m[gi][o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                     self._v[gi][o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
                     self._steps[gi] = int(float(st["step"]))

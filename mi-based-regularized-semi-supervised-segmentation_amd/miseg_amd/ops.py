@@ -292,6 +292,14 @@ def zeros_nhwc(n, c, h, w, dtype, device) -> Tensor:
     return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last).zero_()
 
 
+def _stacked_grad(params, shape, device) -> Tensor:
+    """Gradient buffer for a stacked [S, ...] head parameter: the flat-gradient slots themselves when the S parameters
+    sit back to back there (gradslot.register_adjacent), else a fresh tensor."""
+    from .gradslot import stacked_grad_slot
+    slot = stacked_grad_slot(params) if params else None
+    return slot.view(shape) if slot is not None else torch.empty(shape, dtype=torch.float32, device=device)
+
+
 class _LocalHead(torch.autograd.Function):
     """S x (1x1 conv + channel softmax) with fused sample gather + flip replay -> prob [S,M,K,H,W]."""
 
@@ -302,6 +310,7 @@ class _LocalHead(torch.autograd.Function):
         bsz, c, h, wd = feat.shape
         s, k, _ = w.shape
         m = src.numel()
+        ctx.stack_params = (getattr(w, "_miseg_stack_params", None), getattr(b, "_miseg_stack_params", None))
         w, b = w.contiguous().float(), b.contiguous().float()
         prob = torch.empty(s, m, k, h, wd, dtype=torch.float32, device=feat.device)
         viol = torch.zeros((), dtype=torch.int32, device=feat.device) if k <= 32 else None
@@ -321,8 +330,8 @@ class _LocalHead(torch.autograd.Function):
         m = src.numel()
         gprob = gprob.contiguous().float()
         gfeat = zeros_nhwc(bsz, c, h, wd, feat.dtype, feat.device) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w)
-        gb = torch.empty(s, k, dtype=torch.float32, device=feat.device)
+        gw = _stacked_grad(ctx.stack_params[0], w.shape, feat.device)
+        gb = _stacked_grad(ctx.stack_params[1], (s, k), feat.device)
         ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
         call("miseg_head_local_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
              ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
@@ -352,6 +361,7 @@ class _GlobalHead(torch.autograd.Function):
         bsz, c, h, wd = feat.shape
         s, k, _ = w.shape
         m = src.numel()
+        ctx.stack_params = (getattr(w, "_miseg_stack_params", None), getattr(b, "_miseg_stack_params", None))
         w, b = w.contiguous().float(), b.contiguous().float()
         pooled = torch.empty(m, c, dtype=torch.float32, device=feat.device)
         prob = torch.empty(s, m, k, dtype=torch.float32, device=feat.device)
@@ -369,8 +379,8 @@ class _GlobalHead(torch.autograd.Function):
         m = src.numel()
         gprob = gprob.contiguous().float()
         gfeat = zeros_nhwc(bsz, c, h, wd, dtype, w.device) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w)
-        gb = torch.empty(s, k, dtype=torch.float32, device=w.device)
+        gw = _stacked_grad(ctx.stack_params[0], w.shape, w.device)
+        gb = _stacked_grad(ctx.stack_params[1], (s, k), w.device)
         dz = torch.empty(s * m * k, dtype=torch.float32, device=w.device)
         call("miseg_head_global_bwd", _stream(), _DT[dtype], bsz, h, wd, c, _ptr(src), m, _ptr(w), s, k, temperature, _ptr(pooled),
              _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(dz))

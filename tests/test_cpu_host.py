@@ -181,3 +181,33 @@ def test_trainer_wiring_and_checkpoint_roundtrip(tmp_path):
     tr.load_state_dict_from_path(str(tmp_path / "run"), strict=True)
     assert tr._start_epoch == 4
     torch.testing.assert_close(tr._model.state_dict()["Conv1.conv.0.weight"], sd["_model"]["Conv1.conv.0.weight"])
+
+
+def test_adjacent_head_params_are_stacked_views_of_the_flat_buffers():
+    """gradslot.register_adjacent: sub-head parameters sit back to back in the flat buffers, stacked_param is a view, the
+    gradient arrives per parameter, and the optimiser state keeps the torch parameter order."""
+    import torch
+    from miseg_amd.flat import FlatBuffers
+    from miseg_amd.gradslot import register_adjacent, stacked_param
+    torch.manual_seed(0)
+    heads = torch.nn.ModuleList([torch.nn.Linear(8, 4) for _ in range(3)])
+    other = torch.nn.Linear(4, 4)
+    ws, bs = [h.weight for h in heads], [h.bias for h in heads]
+    register_adjacent(ws)
+    register_adjacent(bs)
+    ref_w = torch.stack([w.detach().clone() for w in ws])
+    assert stacked_param(ws).data_ptr() != ws[0].data_ptr()          # not adjacent yet: plain stack
+    params = [heads[0].weight, heads[0].bias, other.weight, heads[1].weight, heads[1].bias, other.bias, heads[2].weight, heads[2].bias]
+    fb = FlatBuffers(params)
+    fb.build()
+    assert sorted(fb.offsets) == fb.offsets
+    sw, sb = stacked_param(ws), stacked_param(bs)
+    assert sw.data_ptr() == ws[0].data_ptr() and sw.shape == (3, 4, 8) and sb.shape == (3, 4)
+    assert torch.equal(sw, ref_w)
+    coef = torch.randn(3, 4, 8)
+    ((sw * coef).sum() + (sb * 2).sum()).backward()
+    fb.collect()
+    for i in range(3):
+        assert torch.equal(ws[i].grad, coef[i]) and torch.equal(bs[i].grad, torch.full((4,), 2.0))
+        o = fb.offset_of(ws[i])
+        assert torch.equal(fb.flat_grad[o:o + 32].view(4, 8), coef[i])
