@@ -246,6 +246,38 @@ int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, i
 int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     int64_t numel, float beta1, float beta2, const float* hyper);
 
+/* ------------------------------------------------------------------------------------------
+ * Device input pipeline   ref: semi_seg/augment.py:7-52 (ACDCStrongTransforms),
+ * contrastyou/augment/sequential_wrapper.py:11-100, whl:deepclustering2/augment/pil_augment.py
+ * (RandomRotation / RandomCrop / CenterCrop / flips / ToTensor / ToLabel), torchvision 0.7 ColorJitter,
+ * Pillow Image.rotate (NEAREST -> libImaging affine_fixed) and Image.blend.
+ *
+ * atlas_img / atlas_gt : u8 [n_slices, slice_h, slice_w] resident in HBM (atlas_gt may be NULL with gt_out NULL)
+ * jobs_dev             : int32 [njobs, MISEG_AUG_JOB_INTS] on the device, one augmentation job per output slice:
+ *    [0] slice index  [1],[2] unused  [3] number of geometric ops (<= MISEG_AUG_MAX_GEO)  [4] number of colour ops (<= 3)
+ *    [5..7] colour op codes in application order   [8..10] their factors (fp32 bit patterns)   [11] unused
+ *    [12 + 9*g ...] geometric op g in application order: {type, p1..p6, in_w, in_h}:
+ *        MISEG_AUG_CROP   p1 = top, p2 = left                       (out(y,x) = in(y+top, x+left), zero outside)
+ *        MISEG_AUG_VFLIP / MISEG_AUG_HFLIP
+ *        MISEG_AUG_AFFINE p1..p6 = a0,a1,a2,a3,a4,a5 in 16.16 fixed point, a2/a5 already including the half-pixel
+ *                         terms, exactly libImaging's affine_fixed: xin = (a2 + y*a1 + x*a0) >> 16, zero outside
+ *      in_w, in_h = size of the image the op reads.
+ * img_out : fp32 [njobs, out_h, out_w] = u8 / 255 (ToTensor); gt_out : int64 [njobs, out_h, out_w] (ToLabel).
+ * out_h * out_w <= 65536.  Bit-exact against the PIL chain for equal parameters.
+ * ------------------------------------------------------------------------------------------ */
+#define MISEG_AUG_JOB_INTS 48
+#define MISEG_AUG_MAX_GEO 4
+#define MISEG_AUG_CROP 1
+#define MISEG_AUG_VFLIP 2
+#define MISEG_AUG_HFLIP 3
+#define MISEG_AUG_AFFINE 4
+#define MISEG_AUG_BRIGHTNESS 1
+#define MISEG_AUG_CONTRAST 2
+#define MISEG_AUG_SATURATION 3
+int miseg_augment_slices(void* stream, const uint8_t* atlas_img, const uint8_t* atlas_gt, int64_t n_slices,
+                         int64_t slice_h, int64_t slice_w, const int32_t* jobs_dev, int64_t njobs, int64_t out_h,
+                         int64_t out_w, float* img_out, int64_t* gt_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,44 @@ class SyntheticEval:
 
     def __iter__(self):
         return iter(self._batches)
+
+
+def write_acdc_like(root: str, train_patients: int = 8, val_patients: int = 3, height: int = 256, width: int = 256,
+                    num_classes: int = 4, seed: int = 0) -> str:
+    """Write a small dataset in the reference's on-disk format (contrastyou/dataloader/acdc_dataset.py:14-24):
+    ``<root>/ACDC_contrast/{train,val}/{img,gt}/patientNNN_FF_SS.png`` (8-bit 'L' PNGs, gt = class index) plus
+    ``acdc_info.npy`` ({group: slices in the volume}, 200 entries).  Stands in for ACDC where the dataset itself cannot be
+    downloaded (tests, input-pipeline bench)."""
+    import os
+
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    base = os.path.join(root, "ACDC_contrast")
+    info = {}
+    pid = 1
+    for mode, count in (("train", train_patients), ("val", val_patients)):
+        for sub in ("img", "gt"):
+            os.makedirs(os.path.join(base, mode, sub), exist_ok=True)
+        for _ in range(count):
+            for frame in (0, 1):
+                n_slices = int(rng.integers(6, 11))
+                info[f"patient{pid:03d}_{frame:02d}"] = n_slices
+                for s in range(n_slices):
+                    yy, xx = np.mgrid[0:height, 0:width]
+                    cy, cx, r = height / 2 + rng.normal(0, 6), width / 2 + rng.normal(0, 6), 30 + 4 * s
+                    d = np.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+                    gt = np.zeros((height, width), np.uint8)
+                    for c in range(1, num_classes):
+                        gt[d < r * (num_classes - c) / (num_classes - 1)] = c
+                    img = np.clip(40 + 45 * gt + rng.normal(0, 12, gt.shape), 0, 255).astype(np.uint8)
+                    name = f"patient{pid:03d}_{frame:02d}_{s:02d}.png"
+                    Image.fromarray(img, mode="L").save(os.path.join(base, mode, "img", name))
+                    Image.fromarray(gt, mode="L").save(os.path.join(base, mode, "gt", name))
+            pid += 1
+    k = 900
+    while len(info) < 200:      # the reference asserts 200 entries (100 patients x ED/ES)
+        info[f"patient{k:03d}_00"] = 9
+        k += 1
+    np.save(os.path.join(base, "acdc_info.npy"), info, allow_pickle=True)
+    return base
