@@ -31,7 +31,7 @@ FEATURES = ["Conv5", "Up_conv3", "Up_conv2"]
 PEAK = {"mfma_bf16": 2500.0, "mfma_f32": 157.3, "hbm": 8000.0}  # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
 
 
-def build_step(device, lb, ub, size, dtype, rank):
+def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
     from itertools import chain
 
     from contrastyou.arch import UNet
@@ -49,8 +49,19 @@ def build_step(device, lb, ub, size, dtype, rank):
     model, pw = model.to(device), pw.to(device)
     opt = Adam(chain(model.parameters(), pw.parameters()), lr=1e-7 * 400, weight_decay=1e-5)
     torch.manual_seed(rank), random.seed(rank)
-    lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=device)
-    unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=device)
+    if data == "acdc":   # the device input pipeline in the loop: ACDC-format PNG set (synthetic content), 224^2 crops, two fresh views per step
+        import contextlib, io, tempfile
+        from semi_seg import dataloader_helper as DH
+        from semi_seg.synthetic import write_acdc_like
+        root = tempfile.mkdtemp(prefix="miseg_acdc_")
+        write_acdc_like(root, train_patients=20, val_patients=2, height=256, width=256, seed=rank)
+        cfg = {"Data": {"name": "acdc", "labeled_data_ratio": 0.2, "unlabeled_data_ratio": 0.8},
+               "LabeledData": {"shuffle": True, "batch_size": lb}, "UnlabeledData": {"shuffle": True, "batch_size": ub}}
+        with contextlib.redirect_stdout(io.StringIO()):
+            lab, unl, _ = DH.get_dataloaders(cfg, root_dir=root, seed=rank)
+    else:
+        lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=device)
+        unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=device)
     ep = UDAIICEpocher(model, pw, opt, iter(lab), iter(unl), KL_div(verbose=False), torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0,
                        device=device, feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1)
     return ep, opt
@@ -100,6 +111,91 @@ def cpu_baseline(threads):
             "sample": f"{steps} udaiic train steps of the CPU oracle (oracle/step.py), LB=UB={lb}, 256x256, fp32, {dt:.1f} s after one warm-up step"}
 
 
+def input_pipeline_bench(args):
+    """Row 8(f-2): batches from the HBM-resident slices (sampler + parameter draw on the host, one launch per loader)."""
+    import tempfile
+    import numpy as np
+    from semi_seg import dataloader_helper as DH
+    from semi_seg.synthetic import write_acdc_like
+    from miseg_amd import _cabi
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    root = tempfile.mkdtemp(prefix="miseg_acdc_")
+    write_acdc_like(root, train_patients=20, val_patients=2, height=256, width=256, seed=rank)
+    cfg = {"Data": {"name": "acdc", "labeled_data_ratio": 0.2, "unlabeled_data_ratio": 0.8},
+           "LabeledData": {"shuffle": True, "batch_size": args.lb}, "UnlabeledData": {"shuffle": True, "batch_size": args.ub}}
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        lab, unlab, _ = DH.get_dataloaders(cfg, root_dir=root, seed=rank)
+    lab, unlab = iter(lab), iter(unlab)
+    _cabi.lib()
+    real_call, events = _cabi.call, []
+
+    def timed_call(name, *a, **k):
+        if name != "miseg_augment_slices":
+            return real_call(name, *a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        real_call(name, *a, **k)
+        e.record()
+        events.append((s, e))
+
+    def step():
+        return next(lab), next(unlab)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    _cabi.call = timed_call
+    import miseg_amd.slices as SL
+    SL._cabi.call = timed_call
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    SL._cabi.call = _cabi.call = real_call
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    slices = (args.lb + args.ub) * world
+    kern_ms = sum(s.elapsed_time(e) for s, e in events) / len(events)
+    outs = (args.lb + args.ub)                      # outputs per launch pair -> average launch handles (lb+ub) views
+    bytes_per_launch = outs * 224 * 224 * (4 + 8 + 2)   # fp32 image + int64 label written, two u8 gathered, per output pixel
+    line = {"metric": "slices/sec (device input pipeline, 2 augmented views per slice)", "value": round(slices * args.steps / dt, 1),
+            "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"ACDC-format PNG set resident in HBM, pretrain transform (rot45/flips/crop224/ColorJitter) x2 views, "
+                                   f"LB={args.lb} UB={args.ub} per GPU", "parallelism": f"dp{world}"},
+            "roofline": {"kernel": "augment_slices", "bound": "hbm", "achieved": round(bytes_per_launch / (kern_ms * 1e-3) / 1e9, 1),
+                         "peak": 8000.0, "unit": "GB/s", "frac": round(bytes_per_launch / (kern_ms * 1e-3) / 1e9 / 8000.0, 4),
+                         "traffic": None, "avg_ms": round(kern_ms, 4), "launches_per_step": 2,
+                         "note": "latency-bound: 32 blocks on 256 CUs; the host parameter draw dominates the step"}}
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import augment as OA
+        rng = np.random.default_rng(0)
+        img, gt = rng.integers(0, 256, (256, 256), dtype=np.uint8), rng.integers(0, 4, (256, 256), dtype=np.uint8)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            OA.apply("pretrain", img, gt, n)
+            n += 1
+        line["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 1), "unit": "slices/s", "cores": 1, "kind": "port",
+                                "sample": f"{n} slices through the PIL oracle chain (decode excluded), one core, ~10 s"}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +213,17 @@ def main():
                     help="replay the device half of the step as one captured hipGraph (miseg_amd.graph); at the cfg2 shape the step is "
                          "GPU-bound either way (13.6 ms replayed vs 13.5 ms eager), so eager -- with per-kernel events inside the "
                          "timed region -- stays the default")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "acdc"],
+                    help="synthetic = resident ACDC-shaped tensors (BASELINE metric, default); acdc = batches drawn every step by the "
+                         "device input pipeline from an ACDC-format PNG set (224^2 crops, as the reference trains)")
+    ap.add_argument("--workload", default="step", choices=["step", "input"],
+                    help="step = the udaiic train step (BASELINE metric, default); input = the device-resident input pipeline "
+                         "alone (SURVEY.md 8(f-2)): one labeled + one unlabeled batch, two augmented views each")
     args = ap.parse_args()
+    if args.workload == "input":
+        return input_pipeline_bench(args)
+    if args.data == "acdc":
+        args.size = 224   # the reference's crop size (semi_seg/augment.py:13)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,7 +238,7 @@ def main():
     ops.set_mi_precision(mi_prec)
     distributed = ddp.init_from_env("nccl")
 
-    ep, opt = build_step(device, args.lb, args.ub, args.size, args.dtype, rank)
+    ep, opt = build_step(device, args.lb, args.ub, args.size, args.dtype, rank, args.data)
     drv = StepDriver(ep)
     if distributed:
         opt.flat.ensure()
@@ -196,7 +302,8 @@ def main():
             "metric": "images/sec (UNet+IIC fwd/bwd) ACDC 256^2", "value": round(images / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
+            "data": "synthetic" if args.data == "synthetic" else "synthetic ACDC-format PNG set through the device input pipeline (224^2 crops)",
             "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
                                    f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
                        "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,

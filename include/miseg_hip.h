@@ -274,6 +274,31 @@ int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_av
 #define MISEG_AUG_BRIGHTNESS 1
 #define MISEG_AUG_CONTRAST 2
 #define MISEG_AUG_SATURATION 3
+
+/* Host planner: item seeds -> job table, with the reference's random streams (contrastyou/augment/sequential_wrapper.py:27-100;
+ * pil_augment get_params; torchvision 0.7 ColorJitter.get_params; CPython random = MT19937).  Pure host function.
+ * recipe     : the transform preset (semi_seg/augment.py:7-52) in declarative form
+ * item_seeds : SequentialWrapperTwice's global_seed per item (>= 0); slice_ids / widths / heights per item
+ * jobs_out   : HOST int32 [views * n_items, MISEG_AUG_JOB_INTS], view-major (all first views, then all second views)
+ * out_wh     : HOST int32[2] = output width, height (all items must agree, as default_collate demands) */
+#define MISEG_RECIPE_ROTATE 1       /* arg = degrees: uniform(-arg, arg) */
+#define MISEG_RECIPE_VFLIP 2        /* arg = probability */
+#define MISEG_RECIPE_HFLIP 3
+#define MISEG_RECIPE_RANDOM_CROP 4  /* arg = size */
+#define MISEG_RECIPE_CENTER_CROP 5
+typedef struct {
+    int32_t n_geo;
+    int32_t geo_kind[4];
+    double geo_arg[4];
+    int32_t has_jitter;
+    double jitter[6]; /* brightness lo,hi, contrast lo,hi, saturation lo,hi */
+    int32_t twice;
+    int32_t total_freedom;
+} miseg_aug_recipe;
+int miseg_plan_augment(const miseg_aug_recipe* recipe, int64_t n_items, const int64_t* item_seeds,
+                       const int32_t* slice_ids, const int32_t* widths, const int32_t* heights, int32_t* jobs_out,
+                       int32_t* out_wh);
+
 int miseg_augment_slices(void* stream, const uint8_t* atlas_img, const uint8_t* atlas_gt, int64_t n_slices,
                          int64_t slice_h, int64_t slice_w, const int32_t* jobs_dev, int64_t njobs, int64_t out_h,
                          int64_t out_w, float* img_out, int64_t* gt_out);

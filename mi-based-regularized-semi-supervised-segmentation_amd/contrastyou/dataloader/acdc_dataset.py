@@ -131,27 +131,24 @@ class ACDCDataset:
         """What default_collate makes of ``[self[i] for i in indices]`` in the reference (acdc_dataset.py:26-33): a list per
         view of [img batch, target batch], then the filename / partition / group lists -- produced by one launch."""
         res = self.resident()
-        plans_per_view: List[List[S.ViewPlan]] = []
-        for i, seed in zip(indices, item_seeds):
-            w, h = res.sizes[i]
-            views = S.plan_item(self._transform, seed, w, h)
-            if not plans_per_view:
-                plans_per_view = [[] for _ in views]
-            for v, plan in enumerate(views):
-                plans_per_view[v].append(plan)
-        sizes = {(p.out_w, p.out_h) for view in plans_per_view for p in view}
-        if len(sizes) != 1:
-            raise RuntimeError(f"slices of different output sizes in one batch: {sorted(sizes)} (default_collate would fail too)")
-        ow, oh = sizes.pop()
-        flat = [p for view in plans_per_view for p in view]
-        jobs = S.encode_jobs(flat, [i for _ in plans_per_view for i in indices])
+        sizes = [res.sizes[i] for i in indices]
+        jobs, ow, oh = S.plan_native(self._transform, item_seeds, indices, [s[0] for s in sizes], [s[1] for s in sizes])
         img, gt = res.run(jobs, ow, oh)
         n = len(indices)
-        data = [[img[v * n:(v + 1) * n], gt[v * n:(v + 1) * n]] for v in range(len(plans_per_view))]
+        data = [[img[v * n:(v + 1) * n], gt[v * n:(v + 1) * n]] for v in range(2 if self._transform.twice else 1)]
         if not self._transform.twice:
             data = data[0]
-        names = [Path(self._filenames["img"][i]).stem for i in indices]
-        return data, names, [self._get_partition(f) for f in names], [self._get_group(f) for f in names]
+        names, parts, groups = self._meta()
+        return data, [names[i] for i in indices], [parts[i] for i in indices], [groups[i] for i in indices]
+
+    def _meta(self):
+        """(stem, partition, group) per file, computed once per file list."""
+        key = id(self._filenames)
+        if getattr(self, "_meta_key", None) != key:
+            names = [Path(f).stem for f in self._filenames["img"]]
+            self._meta_cache = (names, [self._get_partition(f) for f in names], [self._get_group(f) for f in names])
+            self._meta_key = key
+        return self._meta_cache
 
     def __getitem__(self, index) -> Tuple[list, str, str, str]:
         data, names, parts, groups = self.collate([index], [int(np.random.randint(0, int(1e5)))])

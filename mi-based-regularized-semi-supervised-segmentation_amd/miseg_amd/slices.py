@@ -183,6 +183,54 @@ def encode_jobs(plans: Sequence[ViewPlan], slices: Sequence[int]) -> np.ndarray:
     return jobs
 
 
+# ------------------------------------------------------------------------------------------ native planner
+import ctypes  # noqa: E402
+
+_KIND = {"rotate": 1, "vflip": 2, "hflip": 3, "random_crop": 4, "center_crop": 5}
+
+
+class _CRecipe(ctypes.Structure):   # miseg_aug_recipe (include/miseg_hip.h)
+    _fields_ = [("n_geo", ctypes.c_int32), ("geo_kind", ctypes.c_int32 * 4), ("geo_arg", ctypes.c_double * 4),
+                ("has_jitter", ctypes.c_int32), ("jitter", ctypes.c_double * 6), ("twice", ctypes.c_int32),
+                ("total_freedom", ctypes.c_int32)]
+
+
+def _c_recipe(recipe: Recipe) -> _CRecipe:
+    if len(recipe.geo) > 4:
+        raise ValueError("at most 4 geometric transforms")
+    c = _CRecipe()
+    c.n_geo = len(recipe.geo)
+    for g, (kind, arg) in enumerate(recipe.geo):
+        c.geo_kind[g], c.geo_arg[g] = _KIND[kind], float(arg)
+    c.has_jitter = int(recipe.jitter is not None)
+    if recipe.jitter is not None:
+        for k, (lo, hi) in enumerate(recipe.jitter):
+            c.jitter[2 * k], c.jitter[2 * k + 1] = float(lo), float(hi)
+    c.twice, c.total_freedom = int(recipe.twice), int(recipe.total_freedom)
+    return c
+
+
+_RECIPES: Dict[Recipe, _CRecipe] = {}
+
+
+def plan_native(recipe: Recipe, item_seeds: Sequence[int], slice_ids: Sequence[int], widths: Sequence[int],
+                heights: Sequence[int]) -> Tuple[np.ndarray, int, int]:
+    """The whole batch planned by the C++ twin of plan_item + encode_jobs (csrc/augment_plan.hip, miseg_plan_augment):
+    returns (jobs int32 [views * n, JOB_INTS] view-major, out_w, out_h)."""
+    c = _RECIPES.get(recipe)
+    if c is None:
+        c = _RECIPES[recipe] = _c_recipe(recipe)
+    n = len(item_seeds)
+    views = 2 if recipe.twice else 1
+    seeds = np.asarray(item_seeds, dtype=np.int64)
+    ids, ws, hs = (np.asarray(a, dtype=np.int32) for a in (slice_ids, widths, heights))
+    jobs = np.empty((views * n, JOB_INTS), dtype=np.int32)
+    wh = np.zeros(2, dtype=np.int32)
+    _cabi.call("miseg_plan_augment", ctypes.addressof(c), n, seeds.ctypes.data, ids.ctypes.data, ws.ctypes.data, hs.ctypes.data,
+               jobs.ctypes.data, wh.ctypes.data)
+    return jobs, int(wh[0]), int(wh[1])
+
+
 # ------------------------------------------------------------------------------------------ the resident dataset
 class ResidentSlices:
     """Every slice of a dataset decoded once into u8 atlases [N, Hmax, Wmax] on the device (image and ground truth)."""

@@ -13,6 +13,9 @@ produced by importing and running the reference itself in the build container
 ``tests/test_oracle_golden.py``.  The reference ships no tests or fixtures of
 its own, so those vectors are the pin.
 
+``oracle/augment.py`` (input pipeline) sits on the real Pillow and is pinned by
+``tests/golden/augment.npz`` (reference transform objects run by ``tests/golden/make_golden_augment.py``).
+
 Citations ``path:line`` are relative to the reference checkout; ``whl:`` means
 inside its vendored ``deepclustering2`` wheel.
 """

@@ -141,3 +141,30 @@ def test_acdc_index_split_partitions_and_val_selection(tmp_path):
     assert v2.dataset.show_group_set() <= ug
     with pytest.raises(RuntimeError, match="no CPU path"):
         next(iter(lab))
+
+
+def test_native_planner_equals_python_planner():
+    """csrc/augment_plan.hip (CPython's MT19937 streams, Pillow's matrix set-up, in C++) against miseg_amd.slices.plan_item."""
+    from miseg_amd import slices as S
+    from semi_seg.augment import ACDCStrongTransforms as T
+    rng = np.random.default_rng(0)
+    for name in ("pretrain", "label", "val", "trainval"):
+        rec = getattr(T, name)
+        for (w, h) in [(256, 256), (224, 224), (301, 230), (224, 257)]:
+            seeds = [0, 1, 2, 99999, 100000] + rng.integers(0, 100001, 60).tolist()
+            ids = list(range(len(seeds)))
+            jobs, ow, oh = S.plan_native(rec, seeds, ids, [w] * len(seeds), [h] * len(seeds))
+            plans = [S.plan_item(rec, s, w, h) for s in seeds]
+            views = 2 if rec.twice else 1
+            want = S.encode_jobs([p[v] for v in range(views) for p in plans], ids * views)
+            assert (ow, oh) == (224, 224) and jobs.shape == want.shape
+            assert np.array_equal(jobs, want), (name, w, h, np.argwhere(jobs != want)[:5])
+    big = S.Recipe(geo=(("rotate", 180),), twice=False)       # seeds beyond 32 bits use two key words, as random.seed does
+    seeds = [2 ** 32 + 5, 2 ** 40 + 123, 2 ** 62]
+    jobs, _, _ = S.plan_native(big, seeds, [0, 1, 2], [64] * 3, [64] * 3)
+    assert np.array_equal(jobs, S.encode_jobs([S.plan_item(big, s, 64, 64)[0] for s in seeds], [0, 1, 2]))
+    from miseg_amd._cabi import MisegError
+    with pytest.raises(MisegError, match="RandomCrop"):
+        S.plan_native(T.pretrain, [1], [0], [200], [256])
+    with pytest.raises(MisegError, match="different output sizes"):
+        S.plan_native(S.Recipe(geo=(("vflip", 0.5),)), [1, 2], [0, 1], [64, 65], [64, 64])
