@@ -1,3 +1,3 @@
 from .meters import (AverageValueMeter, EpochResultDict, MeterInterface, MeterResultDict, MultipleAverageValueMeter,  # noqa: F401
-                     UniversalDice)
+                     SurfaceMeter, UniversalDice)
 from .storage import Storage, StorageIncomeDict  # noqa: F401

@@ -128,6 +128,76 @@ class UniversalDice(_Metric):
         return MeterResultDict(rep)
 
 
+def _surface_distances(result: np.ndarray, reference: np.ndarray, voxelspacing=None, connectivity: int = 1) -> np.ndarray:
+    """Distances from the border voxels of ``result`` to the border of ``reference`` -- MedPy 0.4.0
+    ``medpy.metric.binary.__surface_distances`` (requirement.txt:27; not installed here), restated on scipy.ndimage:
+    borders = object XOR its erosion with the ``connectivity`` structuring element, Euclidean distance transform of the
+    complement of the reference border.  Raises RuntimeError on an empty object, as MedPy does."""
+    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
+    result = np.atleast_1d(np.asarray(result).astype(bool))
+    reference = np.atleast_1d(np.asarray(reference).astype(bool))
+    footprint = generate_binary_structure(result.ndim, connectivity)
+    if 0 == np.count_nonzero(result):
+        raise RuntimeError("The first supplied array does not contain any binary object.")
+    if 0 == np.count_nonzero(reference):
+        raise RuntimeError("The second supplied array does not contain any binary object.")
+    result_border = result ^ binary_erosion(result, structure=footprint, iterations=1)
+    reference_border = reference ^ binary_erosion(reference, structure=footprint, iterations=1)
+    dt = distance_transform_edt(~reference_border, sampling=voxelspacing)
+    return dt[result_border]
+
+
+def hausdorff_distance(data1, data2, voxelspacing=None) -> float:
+    """ref whl:deepclustering2/meters2/individual_meters/surface_distance.py:9-14."""
+    hd1 = _surface_distances(data1, data2, voxelspacing, connectivity=1)
+    hd2 = _surface_distances(data2, data1, voxelspacing, connectivity=1)
+    return max(hd1.max(), hd2.max())
+
+
+class SurfaceMeter(_Metric):
+    """Per-slice, per-class Hausdorff distance of class-coded masks (ref whl:.../surface_meter.py:20-145, metername
+    ``hausdorff`` -- the one InferenceEpocher registers).  Host-side scipy work, evaluation only."""
+
+    def __init__(self, C=4, report_axises=None, metername: str = "hausdorff") -> None:
+        assert metername == "hausdorff", metername
+        assert report_axises is None or isinstance(report_axises, (list, tuple))
+        self._C = C
+        self._report_axis = list(report_axises) if report_axises is not None else list(range(C))
+        assert max(self._report_axis) <= C
+        self._abbr = "HD"
+        self.reset()
+
+    def reset(self):
+        self._mhd, self._n = [], 0
+
+    def add(self, pred: Tensor, target: Tensor, voxelspacing=None):
+        assert pred.shape == target.shape, f"incompatible shape of `pred` and `target`, given {pred.shape} and {target.shape}."
+        p = pred.detach().cpu().numpy()
+        t = target.detach().cpu().numpy()
+        out = np.zeros([p.shape[0], len(self._report_axis)])
+        for b in range(p.shape[0]):
+            for k, c in enumerate(self._report_axis):
+                out[b, k] = hausdorff_distance(p[b] == c, t[b] == c, voxelspacing)   # RuntimeError (empty class) aborts the batch
+        self._mhd.append(out)
+        self._n += 1
+
+    def value(self, **kwargs):
+        if self._n == 0:
+            return [np.nan] * self._C, [np.nan] * self._C
+        mhd = np.concatenate(self._mhd, axis=0)
+        return mhd.mean(0), mhd.std(0)
+
+    def summary(self) -> dict:
+        means, _ = self.value()
+        return MeterResultDict({f"{self._abbr}{i}": to_float(means[num]) for num, i in enumerate(self._report_axis)})
+
+    def detailed_summary(self) -> dict:
+        return self.summary()
+
+    def get_plot_names(self) -> List[str]:
+        return [f"{self._abbr}{i}" for i in self._report_axis]
+
+
 class EpochResultDict(dict):
     def __repr__(self):
         return "".join(f"{k}: \n\t{nice_dict(v)}\n" for k, v in self.items())

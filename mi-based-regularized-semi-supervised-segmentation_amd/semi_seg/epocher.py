@@ -26,13 +26,15 @@ from torch import Tensor, nn
 
 from contrastyou.epocher._utils import preprocess_input_with_single_transformation  # noqa
 from contrastyou.epocher._utils import preprocess_input_with_twice_transformation  # noqa
+from contrastyou.epocher._utils import write_img_target, write_predict
 from contrastyou.helper import average_iter, weighted_average_iter
 from contrastyou.trainer._utils import ClusterHead  # noqa
 from deepclustering2.augment.tensor_augment import TensorRandomFlip
 from deepclustering2.decorator import FixRandomSeed
 from deepclustering2.epoch import _Epocher  # noqa
 from deepclustering2.loss import KL_div
-from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterInterface, MultipleAverageValueMeter, UniversalDice)
+from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterInterface, MultipleAverageValueMeter, SurfaceMeter,
+                                     UniversalDice)
 from deepclustering2.optim import get_lrs_from_optimizer
 from deepclustering2.type import T_loader, T_loss, T_optim
 from deepclustering2.utils import class2one_hot
@@ -137,6 +139,45 @@ class EvalEpocher(_num_class_mixin, _Epocher):
     @staticmethod
     def _unzip_data(data, device):
         return preprocess_input_with_single_transformation(data, device)
+
+
+class InferenceEpocher(EvalEpocher):
+    """Evaluation that also dumps image / ground truth / prediction PNGs and reports the per-class Hausdorff distance
+    (ref :76-107).  The argmax + Dice counts stay fused on the device; the PNG writes and the Hausdorff distance
+    (scipy) are host work, as in the reference."""
+
+    def set_save_dir(self, save_dir):
+        self._save_dir = save_dir
+
+    def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
+        meters = super()._configure_meters(meters)
+        meters.register_meter("hd", SurfaceMeter(C=self.num_classes, report_axises=list(range(1, self.num_classes)), metername="hausdorff"))
+        return meters
+
+    @torch.no_grad()
+    def _run(self, *args, **kwargs) -> Tuple[EpochResultDict, float]:
+        self._model.eval()
+        report_dict = EpochResultDict()
+        for _, val_data in zip(self._indicator, self._val_loader):
+            val_img, val_target, file_path, _, group = self._unzip_data(val_data, self._device)
+            val_logits = self._model(val_img)
+            write_img_target(val_img, val_target, self._save_dir, file_path)
+            write_predict(val_logits, self._save_dir, file_path)
+            labels = val_target.squeeze(1)
+            if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
+                val_loss = self._sup_criterion.from_logits(val_logits, labels)
+            else:
+                val_loss = self._sup_criterion(val_logits.softmax(1), class2one_hot(labels, self.num_classes), disable_assert=True)
+            pred, inter, union = ops.argmax_dice(val_logits, labels, want_pred=True)
+            self.meters["loss"].add(val_loss.item())
+            self.meters["dice"].add_counts(inter, union, group_name=group)
+            try:                                   # ref: ExceptionIgnorer(RuntimeError) -- a class absent from a slice
+                self.meters["hd"].add(pred, labels)
+            except RuntimeError:
+                pass
+            report_dict = self.meters.tracking_status()
+            self._indicator.set_postfix_dict(report_dict)
+        return report_dict, self.meters["dice"].summary()["DSC_mean"]
 
 
 class TrainEpocher(_num_class_mixin, _Epocher):

@@ -23,7 +23,7 @@ from deepclustering2.schedulers import GradualWarmupScheduler
 from deepclustering2.trainer import Trainer
 from deepclustering2.type import T_loader, T_loss
 from semi_seg._utils import IICLossWrapper, ProjectorWrapper
-from semi_seg.epocher import (EvalEpocher, IICTrainEpocher, TrainEpocher, UDAIICEpocher, UDATrainEpocher)
+from semi_seg.epocher import (EvalEpocher, IICTrainEpocher, InferenceEpocher, TrainEpocher, UDAIICEpocher, UDATrainEpocher)
 
 __all__ = ["trainer_zoos"]
 
@@ -113,7 +113,11 @@ class SemiTrainer(Trainer):
                 assert checkpoint.exists()
                 checkpoint = checkpoint / "best.pth"
             self.load_state_dict_from_path(str(checkpoint), strict=True)
-        return self.eval_epoch(loader=self._test_loader)
+        evaler = InferenceEpocher(self._model, val_loader=self._test_loader, sup_criterion=self._sup_criterion,
+                                  cur_epoch=self._cur_epoch, device=self._device)
+        evaler.set_save_dir(self._save_dir)
+        result, cur_score = evaler.run()
+        return result, cur_score
 
     @classmethod
     def set_feature_positions(cls, feature_positions):

@@ -211,3 +211,37 @@ def test_adjacent_head_params_are_stacked_views_of_the_flat_buffers():
         assert torch.equal(ws[i].grad, coef[i]) and torch.equal(bs[i].grad, torch.full((4,), 2.0))
         o = fb.offset_of(ws[i])
         assert torch.equal(fb.flat_grad[o:o + 32].view(4, 8), coef[i])
+
+
+def test_surface_meter_hausdorff_against_brute_force():
+    """SurfaceMeter (MedPy 0.4.0 __surface_distances restated on scipy) vs an O(n^2) Hausdorff of the border pixels."""
+    import numpy as np
+    import torch
+    from scipy.ndimage import binary_erosion, generate_binary_structure
+    from deepclustering2.meters2 import SurfaceMeter
+    rng = np.random.default_rng(0)
+
+    def border(m):
+        return m ^ binary_erosion(m, structure=generate_binary_structure(2, 1), iterations=1)
+
+    def brute(a, b):
+        pa, pb = np.argwhere(border(a)), np.argwhere(border(b))
+        d = np.sqrt(((pa[:, None, :] - pb[None, :, :]) ** 2).sum(-1))
+        return max(d.min(1).max(), d.min(0).max())
+
+    pred = torch.zeros(3, 24, 24, dtype=torch.int64)
+    tgt = torch.zeros(3, 24, 24, dtype=torch.int64)
+    for b in range(3):
+        for c in (1, 2):
+            y, x = rng.integers(2, 12, 2)
+            pred[b, y:y + 6 + c, x:x + 5] = c
+            tgt[b, y + 1:y + 8, x + c:x + 7] = c
+    m = SurfaceMeter(C=3, report_axises=[1, 2])
+    m.add(pred, tgt)
+    want = np.array([[brute(pred[b].numpy() == c, tgt[b].numpy() == c) for c in (1, 2)] for b in range(3)])
+    got = m.summary()
+    assert abs(got["HD1"] - want[:, 0].mean()) < 1e-9 and abs(got["HD2"] - want[:, 1].mean()) < 1e-9
+    import pytest
+    with pytest.raises(RuntimeError):                      # an absent class aborts the batch, as MedPy does
+        m.add(torch.zeros(1, 8, 8, dtype=torch.int64), tgt[:1, :8, :8])
+    assert m._n == 1

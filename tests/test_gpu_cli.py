@@ -30,3 +30,30 @@ def test_main_cli_runs_every_trainer(name):
         assert {"config.yaml", "last.pth"} <= files, files
     finally:
         shutil.rmtree(run_dir, ignore_errors=True)
+
+
+def test_trainer_inference_dumps_pngs_and_reports_hausdorff(tmp_path):
+    """SemiTrainer.inference (ref semi_seg/trainer.py:109-124 -> InferenceEpocher, epocher.py:76-107)."""
+    sys.path.insert(0, PKG)
+    import torch
+    from contrastyou.arch import UNet
+    from deepclustering2.loss import KL_div
+    from semi_seg.synthetic import SyntheticEval, SyntheticPairs
+    from semi_seg.trainer import trainer_zoos
+    cfg = {"Optim": {"name": "Adam", "lr": 1e-4, "weight_decay": 1e-5},
+           "Trainer": {"feature_names": ["Conv5", "Up_conv3", "Up_conv2"], "feature_importance": [1, 0.5, 0.5], "max_epoch": 1}}
+    tr = trainer_zoos["partial"](
+        model=UNet(input_dim=1, num_classes=4), labeled_loader=iter(SyntheticPairs(2, 64, 4, seed=0)),
+        unlabeled_loader=iter(SyntheticPairs(2, 64, 4, seed=1)), val_loader=SyntheticEval(1, 2, 64, 4, seed=2),
+        test_loader=SyntheticEval(2, 3, 64, 4, seed=3), sup_criterion=KL_div(), configuration=cfg, save_dir=str(tmp_path / "run"),
+        max_epoch=1, num_batches=2, device="cuda")
+    tr.init()
+    tr.start_training()
+    result, score = tr.inference()
+    assert 0.0 <= score <= 1.0 and "dice" in result and "hd" in result
+    for sub in ("img", "gt", "pred"):
+        assert len(os.listdir(tmp_path / "run" / sub)) == 6
+    from PIL import Image
+    import numpy as np
+    name = sorted(os.listdir(tmp_path / "run" / "pred"))[0]
+    assert np.array(Image.open(tmp_path / "run" / "pred" / name)).max() <= 3
