@@ -5,9 +5,12 @@
 //   out[o][h][w'] = sum_b dA[(b,o), w' -+ (b-p)]                                 "col2im"
 // Block = 512 threads = 8 waves = 2 waves per SIMD, so one wave's LDS / col2im / global phases overlap its SIMD partner's
 // MFMAs.  Wave w: output row (w & 3) of the item's 4 rows, M half (w >> 2) -- the two halves of a row sit on the same SIMD.
-//   * A (the gradient matrix Gm) is packed once per call into bf16 hi/lo k-step slices [dir][ks][plane][144][32] (row-swizzled)
-//     and streamed L2 -> registers -> LDS one slice ahead of the MFMAs, as one continuous double-buffered pipeline across
-//     items (one __syncthreads per k-step);
+//   * A (the gradient matrix Gm) is packed once per call into bf16 hi/lo k-step slices [dir][ks][plane][144][32]; every wave
+//     loads its own A fragments straight from L2/L1 into registers (1 KiB coalesced buffer loads, one k-step ahead of the
+//     MFMAs, the first k-step of the next item during the last of this one).  Nothing in LDS changes during the k-loop, so the
+//     loop has NO workgroup barrier and the two waves of a SIMD drift apart: one's LDS / col2im phases hide under the other's
+//     MFMAs (an earlier version staged A through a double-buffered LDS slice with a barrier per k-step: all eight waves then
+//     moved in lockstep, MFMA and LDS phases serialised, 22 k cycles per item for 8.6 k cycles of MFMA);
 //   * B: the source tile stays planar [c][row][w] in LDS; ds_read_b64_tr_b16 transposes 4 planes x 16 pixels on the fly into
 //     the 8-consecutive-k lane layout.  Rows live in a 12-row ring (3 groups of 4): a block walks a segment of consecutive
 //     4-row items down one 58-column strip and fetches only the 4 new rows per item (registers, one item ahead);
@@ -22,12 +25,19 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
 
+// Profiling builds only (-DMISEG_BWD_ABLATE=bits: 1 no src tile, 2 no MFMA, 4 no col2im, 8 no output write, 16 no A loads).  Compile-time
+// so that the shipped kernel's item body is straight-line code: any branch inside it makes the compiler fall back to vmcnt(0)
+// at the next wait, which drains the A-fragment prefetches the loop keeps in flight.
+#ifndef MISEG_BWD_ABLATE
+#define MISEG_BWD_ABLATE 0
+#endif
+constexpr int kAbl = MISEG_BWD_ABLATE;
+
 struct Bwd3Geom {
     int N, H, W, P, G, accumulate;
     int L;        // items (4-row tiles) per segment
     int S;        // sub-heads in this launch: operands / outputs of head s at + s * hs elements, G and scale rows s * P + p
     long long hs;
-    int ablate;   // profiling only (MISEG_ABLATE): 1 no src tile, 2 no MFMA, 4 no col2im, 8 no output write, 16 no G streaming
 };
 
 template <int K, int PAD>
@@ -67,7 +77,7 @@ __global__ void pack_g_bf16_kernel(const float* __restrict__ grad_raw, int P, un
     }
 }
 
-template <int K, int PAD, int NTERMS>
+template <int K, int PAD, int NTERMS, bool ACC>
 __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ y, Bwd3Geom g,
                                                                 const int32_t* __restrict__ win,
                                                                 const unsigned short* __restrict__ gpack,
@@ -79,14 +89,14 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
     constexpr int SLICE = NP * MP * 32;                  // bf16 elements per k-step slice
     constexpr int SPLANE = K * RING * SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    unsigned short* Gsl = reinterpret_cast<unsigned short*>(ldsb);               // [2][NP][MP][32]
-    unsigned short* Ss = Gsl + 2 * SLICE;                                        // [NP][K][RING][SW]
+    unsigned short* Ss = reinterpret_cast<unsigned short*>(ldsb);                // [NP][K][RING][SW]
     float* Dst = reinterpret_cast<float*>(Ss + NP * SPLANE);                     // [8 waves][64 cols][DL]
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r4 = wvu & 3, half = wvu >> 2;
     float* Dw = Dst + (size_t)wvu * WT * DL;
-    const float* Dpartner = Dst + (size_t)(wvu + 4) * WT * DL;                   // half 1 of the same row (read by half 0 only)
+    float* Park = Dst + (size_t)8 * WT * DL;                                     // [2 item parities][4 rows][64 cols][DL]: half 1 -> half 0
+    int itc = 0;                                                                 // items done by this block
     const size_t plane = (size_t)g.H * g.W;
 
     // ---- segments: (dir, window p, sample n, column strip ct, run of <= L consecutive 4-row items)
@@ -124,18 +134,18 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
     constexpr int PFN = (K * 4) / 8;
     const unsigned tbytes = (unsigned)((size_t)g.N * K * plane * 4);
     constexpr unsigned OOB = 0xC0000000u;
-    auto fetch_group = [&](const Seg& o, int j, float* dst) {
-        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)o.s * g.hs), 0, (int)tbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)o.s * g.hs), 0, (int)tbytes, 0x00020000);
+    auto fetch_group = [&](const Seg& o, int j, float* dst, bool live = true) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((o.dir ? x : y) + (size_t)o.s * g.hs), 0, (int)tbytes, 0x00020000);
         const int col = o.col0 - PAD + lane;
         const unsigned vo = (col >= o.w0 && col < o.w1) ? (unsigned)col * 4u : OOB;
 #pragma unroll
         for (int i = 0; i < PFN; ++i) {
             const int pr = wvu + 8 * i, ch = pr >> 2, r = pr & 3, row = o.h0 + 4 * j + r;
-            const bool ok = row >= o.h0 && row < o.h1;
-            const unsigned so = ok ? (unsigned)((((size_t)o.n * K + ch) * plane + (size_t)row * g.W) * 4) : OOB;
-            dst[i] = __uint_as_float(o.dir ? __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)(so + vo), 0, 0)
-                                           : __builtin_amdgcn_raw_buffer_load_b32(rsy, (int)(so + vo), 0, 0));
+            const bool ok = live && row >= o.h0 && row < o.h1;
+            // 32-bit arithmetic (tensor < 1 GiB, checked on the host), computed unconditionally so that `ok` is a scalar select, not a branch
+            const unsigned lin = ((unsigned)(o.n * K + ch) * (unsigned)plane + (unsigned)row * (unsigned)g.W) * 4u;
+            const unsigned so = ok ? lin : OOB;
+            dst[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(so + vo), 0, 0));
         }
     };
     auto commit_group = [&](int slot, const float* src) {
@@ -148,60 +158,60 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
             if (NP == 2) d[SPLANE] = bf16_hi(src[i] - bf16_bits_to_f32(hi));
         }
     };
-    // ---- G slice streaming: SLICE/8 uint4 per slice
-    constexpr int GQ = (SLICE / 8 + 511) / 512;
-    u32x4 gq[GQ];
-    auto gload = [&](const unsigned short* slice) {
-#pragma unroll
-        for (int i = 0; i < GQ; ++i) {
-            const int idx = tid + 512 * i;
-            if (idx < SLICE / 8) gq[i] = *reinterpret_cast<const u32x4*>(slice + (size_t)idx * 8);
-        }
-    };
-    auto gstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < GQ; ++i) {
-            const int idx = tid + 512 * i;
-            if (idx < SLICE / 8) *reinterpret_cast<u32x4*>(Gsl + (size_t)buf * SLICE + (size_t)idx * 8) = gq[i];
-        }
-    };
     auto slices_of = [&](const Seg& o) { return gpack + (size_t)((o.s * g.P + o.p) * 2 + o.dir) * KS * SLICE; };
 
     // pending output of the previous item (kept in registers until the partner half's partial is visible)
     float outp[K];
     int prow = 0, pcol0 = 0, pn = 0, pdir = 0, ph1 = 0, pw1 = 0, pp = 0, ps = 0;
     bool pending = false;
+    // Branch-free: a lane without an output (tile halo, past the window, nothing pending yet) stores to an out-of-range buffer
+    // offset, which the hardware drops.
     auto finish_output = [&]() {
-        if (!pending || half != 0) return;
+        const float* Dpartner = Park + (size_t)((((itc - 1) & 1) * 4 + r4) * WT) * DL;   // parked by the row's half-1 wave last item
 #pragma unroll
         for (int o4 = 0; o4 < K; o4 += 4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(Dpartner + lane * DL + o4);
             outp[o4] += v[0]; outp[o4 + 1] += v[1]; outp[o4 + 2] += v[2]; outp[o4 + 3] += v[3];
         }
         const int col = pcol0 + lane - PAD;
-        if (prow < ph1 && lane >= PAD && lane < PAD + C::WB && col < pw1 && !((g.ablate & 8) && outp[0] != 12345.f)) {
-            const float sc = scale[ps * g.P + pp];
-            float* op = (pdir ? gy : gx) + (size_t)ps * g.hs + (size_t)pn * K * plane + (size_t)prow * g.W + col;
-            if (g.accumulate) {
-                float old[K];
+        const bool live = pending && prow < ph1 && lane >= PAD && lane < PAD + C::WB && col < pw1 && !(kAbl & 8);
+        const float sc = scale[ps * g.P + pp];
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)((pdir ? gy : gx) + (size_t)ps * g.hs), 0, (int)tbytes, 0x00020000);
+        const unsigned vo = live ? (unsigned)(((size_t)pn * K * plane + (size_t)prow * g.W + col) * 4) : OOB;
+        const unsigned pl4 = (unsigned)(plane * 4);
+        if (ACC) {
+            float old[K];
 #pragma unroll
-                for (int o = 0; o < K; ++o) old[o] = op[(size_t)o * plane];
+            for (int o = 0; o < K; ++o) old[o] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)vo, (int)(o * pl4), 0));
 #pragma unroll
-                for (int o = 0; o < K; ++o) op[(size_t)o * plane] = old[o] + sc * outp[o];
-            } else {
+            for (int o = 0; o < K; ++o) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old[o] + sc * outp[o]), rso, (int)vo, (int)(o * pl4), 0);
+        } else {
 #pragma unroll
-                for (int o = 0; o < K; ++o) op[(size_t)o * plane] = sc * outp[o];
-            }
+            for (int o = 0; o < K; ++o) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc * outp[o]), rso, (int)vo, (int)(o * pl4), 0);
         }
     };
 
     const int64_t nseg = 2 * total;
     Seg sg, sgn_;
-    int par = 0;   // G buffer holding the slice of the upcoming k-step
+    // A fragments: "step" = (k-step, M tile) in execution order; a wave keeps the fragments of AHEAD steps in flight in a ring
+    // of AHEAD + 1 register slots, across item boundaries (a0 = the first AHEAD steps of the upcoming item).
+    constexpr int AHEAD = 2;
+    u32x4 a0[AHEAD][NP];
+    const int aoff0 = ((l15 * 32) + 8 * (q ^ ((0 - (l15 >> 2)) & 3))) * 2;      // byte offset of this lane's 16 B inside an M tile
+    auto rsrc_of = [&](const unsigned short* slices) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)slices, 0, KS * SLICE * 2, 0x00020000);
+    };
+    auto load_step = [&](__amdgpu_buffer_rsrc_t rs, int mt0, int mtn, int step, u32x4* dst) {
+        const int ks = step / mtn, ml = step - ks * mtn;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+            dst[pl] = (kAbl & 16) ? u32x4{0u, 0u, 0u, 0u}
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rs, aoff0, (ks * SLICE + (pl * MP + (mt0 + ml) * 16) * 32) * 2, 0);
+    };
     if ((int64_t)blockIdx.x < nseg) {
         decode(blockIdx.x, sg);
-        gload(slices_of(sg));
-        gstore(0);
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) load_step(rsrc_of(slices_of(sg)), half ? MH : 0, half ? MT - MH : MH, i, a0[i]);
     }
 #pragma unroll 1
     for (int64_t sid = blockIdx.x; sid < nseg; sid += g.G) {
@@ -209,10 +219,8 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
         if (more_seg) decode(sid + g.G, sgn_);
         const int dir = sg.dir, sgn = dir ? 1 : -1;
         const unsigned short* gbase = slices_of(sg);
-        __syncthreads();                         // previous item: MFMA phase done with Ss, partner partials written
-        finish_output();
-        pending = false;
-        if (!(g.ablate & 1)) {                   // warm the ring: groups rt0-1, rt0, rt0+1
+        lds_barrier();                           // previous item: every wave is done with the ring, partials are parked
+        if (!(kAbl & 1)) {                   // warm the ring: groups rt0-1, rt0, rt0+1
             float w3[3][PFN];
 #pragma unroll
             for (int u = 0; u < 3; ++u) fetch_group(sg, sg.rt0 - 1 + u, w3[u]);
@@ -224,13 +232,21 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
 #pragma unroll 1
         for (int rt = sg.rt0; rt < sg.rt1; ++rt) {
             if (rt > sg.rt0) {
-                __syncthreads();
-                finish_output();
-                pending = false;
-                if (!(g.ablate & 1)) commit_group((base3 + 2) % 3, pf);       // group rt+1 replaces group rt-2
+                lds_barrier();
+                if (!(kAbl & 1)) commit_group((base3 + 2) % 3, pf);       // group rt+1 replaces group rt-2
             }
+            // Retire the previous item here (half-0 waves: partner partials + global stores): every wave is between the two
+            // barriers anyway, the stores get a head start of a whole B-fragment read burst on the first A-fragment wait (vmcnt
+            // retires in order), and the 20 output registers are dead during the k-loop.
+            if (half == 0) finish_output();
+            lds_barrier();                       // ring commits visible
+            // From here to the next item's barrier the waves run free (no workgroup barrier inside the k-loop).
             const bool more_rt = rt + 1 < sg.rt1;
-            if (more_rt && !(g.ablate & 1)) fetch_group(sg, rt + 2, pf);
+            // The rows of item rt+1 are fetched at the start of the LAST k-step: vmcnt retires in order, so loads issued before the
+            // k-loop would sit in front of every A-fragment wait; issued here only the next item's first fragments queue behind them.
+            auto late_work = [&]() {
+                if (!(kAbl & 1)) fetch_group(sg, rt + 2, pf, more_rt);
+            };
             auto body = [&](auto HC) {
                 constexpr int HALF = decltype(HC)::value;
                 constexpr int MT0 = HALF ? MH : 0, MTN = HALF ? MT - MH : MH;
@@ -239,16 +255,19 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                 for (int ml = 0; ml < MTN; ++ml)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[ml][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+                const unsigned short* nxt_slices = more_rt ? gbase : more_seg ? slices_of(sgn_) : nullptr;
+                const __amdgpu_buffer_rsrc_t rsA = rsrc_of(gbase);
+                const __amdgpu_buffer_rsrc_t rsN = rsrc_of(nxt_slices != nullptr ? nxt_slices : gbase);
+                constexpr int NS = KS * MTN;
+                static_assert(NS > AHEAD, "ring assumes more steps per item than it prefetches");
+                u32x4 ring[AHEAD + 1][NP];
+#pragma unroll
+                for (int i = 0; i < AHEAD; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) ring[i][pl] = a0[i][pl];
+#pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    lds_barrier();               // slice `par` (and any ring commit) visible; everyone done with slice par^1
-                    const unsigned short* nxt = ks + 1 < KS ? gbase + (size_t)(ks + 1) * SLICE
-                                                : more_rt   ? gbase
-                                                : more_seg  ? slices_of(sgn_)
-                                                            : nullptr;
-                    const bool stream = nxt != nullptr && !((g.ablate & 16) && ks + 1 < KS);
-                    if (stream) gload(nxt);
-                    const unsigned short* Gb = Gsl + (size_t)par * SLICE;
+                    if (ks == KS - 1) late_work();
                     // B fragments: kred block of 8 = two 4-blocks kb, kb+4; 4-block -> (a, c0..c0+3) never straddles a (K % 4 == 0)
                     bf16x8_t bfr[NP][NT];
                     {
@@ -273,14 +292,17 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                                 bfr[pl][nt] = __builtin_bit_cast(bf16x8_t, f);
                             }
                     }
-                    if (!(g.ablate & 2))
+                    if (!(kAbl & 2))
 #pragma unroll
                         for (int ml = 0; ml < MTN; ++ml) {
-                            const int m = (MT0 + ml) * 16 + l15;
+                            constexpr int dummy2 = 0; (void)dummy2;
+                            const int step = ks * MTN + ml;                    // compile-time after unrolling
+                            if (step + AHEAD < NS) load_step(rsA, MT0, MTN, step + AHEAD, ring[(step + AHEAD) % (AHEAD + 1)]);
+                            else load_step(rsN, MT0, MTN, step + AHEAD - NS, ring[(step + AHEAD) % (AHEAD + 1)]);   // no next item: re-reads this one
+                            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch where it is: the scheduler would sink it next to its use
                             bf16x8_t af[NP];
 #pragma unroll
-                            for (int pl = 0; pl < NP; ++pl)
-                                af[pl] = *reinterpret_cast<const bf16x8_t*>(Gb + ((size_t)pl * MP + m) * 32 + 8 * (q ^ ((0 - (m >> 2)) & 3)));
+                            for (int pl = 0; pl < NP; ++pl) af[pl] = __builtin_bit_cast(bf16x8_t, ring[step % (AHEAD + 1)][pl]);
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
                                 if (NTERMS == 3) {
@@ -290,13 +312,15 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                                 acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[0][nt], acc[ml][nt], 0, 0, 0);
                             }
                         }
-                    if (stream) gstore(par ^ 1);
-                    if (nxt != nullptr) par ^= 1;
                 }
+#pragma unroll
+                for (int i = 0; i < AHEAD; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) a0[i][pl] = ring[(NS + i) % (AHEAD + 1)][pl];
                 // ---- col2im gather: lane = output tile column wc; out[o] += D[(b,o)][wc + sgn*(b-PAD)]
 #pragma unroll
                 for (int o = 0; o < K; ++o) outp[o] = 0.f;
-                if (g.ablate & 4) {
+                if (kAbl & 4) {
 #pragma unroll
                     for (int ml = 0; ml < MTN; ++ml)
 #pragma unroll
@@ -306,8 +330,9 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                     for (int ml = 0; ml < MTN; ++ml) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(Dw + (nt * 16 + l15) * DL + 4 * q) = acc[ml][nt];
+                        // same-wave LDS traffic is serviced in issue order: a compiler barrier is all the staging needs
                         __builtin_amdgcn_wave_barrier();
-                        __threadfence_block();
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int rq = 0; rq < 4; ++rq) {
                             constexpr int dummy = 0; (void)dummy;
@@ -315,39 +340,41 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                             if (m < C::MD) {
                                 const int b = m / K, o = m % K;
                                 const int src_col = lane + sgn * (b - PAD);
-                                if (src_col >= 0 && src_col < WT) {
-                                    const f32x4 v = *reinterpret_cast<const f32x4*>(Dw + src_col * DL + 4 * rq);
-                                    outp[o] += v[0]; outp[o + 1] += v[1]; outp[o + 2] += v[2]; outp[o + 3] += v[3];
-                                }
+                                const bool in = src_col >= 0 && src_col < WT;
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(Dw + (in ? src_col : lane) * DL + 4 * rq);
+                                outp[o] += in ? v[0] : 0.f; outp[o + 1] += in ? v[1] : 0.f;
+                                outp[o + 2] += in ? v[2] : 0.f; outp[o + 3] += in ? v[3] : 0.f;
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
-                        __threadfence_block();
+                        asm volatile("" ::: "memory");
                     }
                 }
-                if (HALF == 1) {                 // park the partial sums for the row's half-0 wave: Dw[col][o]
+                if (HALF == 1) {                 // park the partial sums for the row's half-0 wave
+                    float* pk = Park + (size_t)(((itc & 1) * 4 + r4) * WT) * DL;
 #pragma unroll
                     for (int o4 = 0; o4 < K; o4 += 4)
-                        *reinterpret_cast<f32x4*>(Dw + lane * DL + o4) = f32x4{outp[o4], outp[o4 + 1], outp[o4 + 2], outp[o4 + 3]};
+                        *reinterpret_cast<f32x4*>(pk + lane * DL + o4) = f32x4{outp[o4], outp[o4 + 1], outp[o4 + 2], outp[o4 + 3]};
                 }
             };
             if (half == 0) body(std::integral_constant<int, 0>{});
             else body(std::integral_constant<int, 1>{});
             prow = sg.h0 + 4 * rt + r4; pcol0 = sg.col0; pn = sg.n; pdir = dir; ph1 = sg.h1; pw1 = sg.w1; pp = sg.p; ps = sg.s;
             pending = true;
+            ++itc;
             base3 = base3 == 2 ? 0 : base3 + 1;
         }
         sg = sgn_;
     }
     __syncthreads();
-    finish_output();
+    if (half == 0) finish_output();
 }
 
 template <int K, int PAD>
 static size_t bwd3_lds(int nterms) {
     typedef B3<K, PAD> C;
     const int np = nterms == 1 ? 1 : 2;
-    return (size_t)2 * np * C::MP * 32 * 2 + (size_t)np * K * C::RING * C::SW * 2 + (size_t)8 * C::WT * C::DL * 4;
+    return (size_t)np * K * C::RING * C::SW * 2 + (size_t)(8 + 2 * 4) * C::WT * C::DL * 4;
 }
 
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad) {
@@ -368,21 +395,19 @@ static int launch_bwd3(hipStream_t st, const float* x, const float* y, Bwd3Geom 
     if (nterms == 1) hipLaunchKernelGGL((pack_g_bf16_kernel<K, PAD, 1>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, g.P * g.S, gpack);
     else hipLaunchKernelGGL((pack_g_bf16_kernel<K, PAD, 2>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, g.P * g.S, gpack);
     const size_t lds = bwd3_lds<K, PAD>(nterms);
-    if (nterms == 1) {
-        hipFuncSetAttribute((const void*)local_bwd_bf16_kernel<K, PAD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_bwd_bf16_kernel<K, PAD, 1>), dim3(g.G), dim3(512), lds, st, x, y, g, win, gpack, scale, gx, gy);
-    } else {
-        hipFuncSetAttribute((const void*)local_bwd_bf16_kernel<K, PAD, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_bwd_bf16_kernel<K, PAD, 3>), dim3(g.G), dim3(512), lds, st, x, y, g, win, gpack, scale, gx, gy);
-    }
+    auto go = [&](auto kernel) {
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(g.G), dim3(512), lds, st, x, y, g, win, gpack, scale, gx, gy);
+    };
+    if (nterms == 1) g.accumulate ? go(local_bwd_bf16_kernel<K, PAD, 1, true>) : go(local_bwd_bf16_kernel<K, PAD, 1, false>);
+    else g.accumulate ? go(local_bwd_bf16_kernel<K, PAD, 3, true>) : go(local_bwd_bf16_kernel<K, PAD, 3, false>);
     return 0;
 }
 
 int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
                           const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
                           void* ws, int nterms) {
-    Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate, 8, (int)S, (long long)hs, 0};
-    { const char* ab = getenv("MISEG_ABLATE"); g.ablate = ab ? atoi(ab) : 0; }
+    Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate, 8, (int)S, (long long)hs};
     if (P == 1) {   // one whole-image window (the shipped configuration): pick the segment length with the best block balance
         const int wb = 64 - 2 * (int)pad, tr = ((int)H + 3) / 4, tc = ((int)W + wb - 1) / wb;
         double best = 1e30;
