@@ -32,21 +32,39 @@ __device__ __forceinline__ void split_store(float v, unsigned short* hi, unsigne
     if (lo) *lo = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
 }
 
-constexpr int kBT = 256;        // 4 waves = 2 pairs, one wave per SIMD (512-register budget: D tiles + prefetch registers)
+constexpr int kBT = 512;        // 8 waves = 2 quads, two waves per SIMD: each SIMD hosts one wave of each quad
+
+// The MT x NT tiles of D in row-major order, cut into four runs: wave `ROLE` of a quad owns one run (~MT*NT/4 accumulator
+// tiles = 84 registers at 9 x 9), so two waves fit a SIMD and one's LDS phases can hide under the other's MFMAs.
+template <int MT, int NT, int ROLE>
+struct QuadTiles {
+    static constexpr int PER = (MT * NT + 3) / 4;
+    static constexpr bool mine(int m, int n) { return (m * NT + n) / PER == ROLE; }
+    static constexpr bool row_used(int m) {
+        for (int n = 0; n < NT; ++n)
+            if (mine(m, n)) return true;
+        return false;
+    }
+    static constexpr bool col_used(int n) {
+        for (int m = 0; m < MT; ++m)
+            if (mine(m, n)) return true;
+        return false;
+    }
+};
 
 template <int MT, int NT, int PAD, int NTERMS, int ROLE>
 __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mask,
                                                 const JointGeom& g, const int32_t* __restrict__ win, float* __restrict__ partials,
                                                 unsigned char* lds) {
-    typedef TileSet<MT, NT, ROLE> TS;
+    typedef QuadTiles<MT, NT, ROLE> TS;
     constexpr int T = 2 * PAD + 1, NP = NTERMS == 1 ? 1 : 2, RBY = BRB + 2 * PAD;
     const int K = g.K;
     // LDS carve (bf16 = unsigned short)
     unsigned short* Xr = reinterpret_cast<unsigned short*>(lds);                 // [NP][K][BRB][BXW]
     unsigned short* Ys = Xr + (size_t)NP * K * BRB * BXW;                        // [NP][K][RBY][BYW]
-    unsigned short* Asb = Ys + (size_t)NP * K * RBY * BYW;                       // [2 pairs][NP][T][K][BAW]
+    unsigned short* Asb = Ys + (size_t)NP * K * RBY * BYW;                       // [2 quads][NP][T][K][BAW]
     const size_t xPlane = (size_t)K * BRB * BXW, yPlane = (size_t)K * RBY * BYW, aPlane = (size_t)T * K * BAW;
-    const int tid = threadIdx.x, lane = tid & 63, pair = tid >> 7, ptid = tid & 127, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, pair = tid >> 8, ptid = tid & 255, wv = tid >> 6;   // pair = quad index
     const int l15 = lane & 15, q = lane >> 4;
     unsigned short* As = Asb + (size_t)pair * NP * aPlane;
 
@@ -59,17 +77,14 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
     const int nItems = g.N * tr * tc;
     const int mtu = g.tilesM, ntu = g.tilesM;
 
-    int aoff[MT], boff[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    auto aoff = [&](int mt) {                             // m = dx*K + i is exactly the As row index; swizzled 16-B slot
         const int m = min(mt * 16 + l15, g.Mdim - 1);
-        aoff[mt] = m * BAW + 8 * (q ^ ((m >> 2) & 3));    // m = dx*K + i is exactly the As row index; swizzled slot
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+        return m * BAW + 8 * (q ^ ((m >> 2) & 3));
+    };
+    auto boff = [&](int nt) {
         const int c = min(nt * 16 + l15, g.Mdim - 1);
-        boff[nt] = ((c % K) * RBY + (2 * PAD - c / K)) * BYW + 8 * q;
-    }
+        return ((c % K) * RBY + (2 * PAD - c / K)) * BYW + 8 * q;
+    };
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -77,61 +92,107 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const size_t plane = (size_t)g.H * g.W;
-    // ---- register-staged prefetch: each wave owns (ch,row) pairs pr = wv, wv+4, ...  (K*BRB/4 <= 20 X rows, K*RBY/4 <= 50 Y rows)
-    constexpr int XB = 20, YB = 50;
-    float xv[XB], xe[XB], yv[YB];
-    const int nxr = K * BRB, nyr = K * RBY;
-    // Buffer loads: one descriptor per tensor, a 32-bit byte offset per load (row part wave-uniform, column part
-    // per lane) and hardware range checking: an out-of-window row/column is given an out-of-range offset and reads 0.
-    // (64-bit flat addresses for ~90 in-flight loads cost 180 address registers and spilled.)
+    // ---- register-staged prefetch.  Every load is a b64 (two adjacent pixels per lane) and every LDS store a packed bf16 pair:
+    // half the VMEM and DS instructions of a pixel-per-lane scheme (the commit was LDS-store bound: 720 ds_write_b16 per item).
+    //   X main  : unit U = wave + 8*bi covers rows pr = 2U, 2U+1 (lane half) x 64 px; (ch, r) = (U / 2 + ..., 2 (U & 1) + half)
+    //   X extra : unit E covers 8 rows x 16 px (8 lanes each): E = wave (and 8 + wave for waves 0, 1)
+    //   Y       : unit U = wave + 8*bi covers rows 2U, 2U+1 of the [K][RBY] row list (RBY even: both in one channel)
+    // Row patterns repeat with a fixed channel stride (see YPER below), so addresses are running sums; one descriptor per sample
+    // makes channels >= K read 0, an invalid row gets the out-of-range marker as its base.
+    static_assert(BRB == 4 && RBY % 2 == 0, "row pairing assumes 4 X rows and an even number of Y rows per channel");
+    constexpr int XB = 5, XE = 2, YH = RBY / 2;             // X units per wave (K*4/2/8 <= 5), extra units, Y row pairs per channel
+    constexpr int YPER = YH % 8 == 0 ? 1 : YH % 4 == 0 ? 2 : YH % 2 == 0 ? 4 : YH;   // lcm(8, YH) / 8
+    constexpr int YCST = 8 * YPER / YH;                     // channels advanced per period
+    constexpr int YB = (20 * YH + 7) / 8;                   // Y units per wave for K <= 20
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    f32x2 xv[XB], xe[XE], yv[YB];
     const unsigned tbytes = (unsigned)((size_t)g.N * K * plane * 4);
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)tbytes, 0x00020000);
+    (void)tbytes;
     constexpr unsigned OOB = 0xC0000000u;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned pl4 = (unsigned)(plane * 4);
+    const int half = lane >> 5, l31 = lane & 31;
+    int pcol0 = 0;                                          // column origin of the prefetched item (for the edge masks at commit)
+    auto ld2 = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vo, (int)so, 0);
+        return f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+    };
     auto prefetch = [&](int it) {
         const int ct = it % tc, rt = (it / tc) % tr, n = it / (tc * tr);
         const int row0 = h0 + rt * BRB, col0 = w0 + ct * BKW;
-        const int colx = col0 - 8 + lane, cole = colx + 64, coly = col0 + lane;
-        const unsigned vx = (colx >= w0 && colx < w1) ? (unsigned)colx * 4u : OOB;
-        const unsigned ve = (lane < 16 && cole >= w0 && cole < w1) ? (unsigned)cole * 4u : OOB;
-        const unsigned vy = (coly < w1) ? (unsigned)coly * 4u : OOB;
+        pcol0 = col0;
+        const unsigned sbytes = (unsigned)K * pl4;
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)n * K * plane), 0, (int)sbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)n * K * plane), 0, (int)sbytes, 0x00020000);
+        const unsigned wb = (unsigned)g.W * 4u;
+        {   // X main: U = wvu + 8*bi: ch = U >> 1 = (wvu >> 1) + 4*bi, r = 2 * (wvu & 1) + half
+            const int r = 2 * (wvu & 1) + half, row = row0 + r, col = col0 - 8 + 2 * l31;
+            const bool ok = row < h1 && col + 1 >= w0 && col < w1 && col >= 0;
+            const unsigned vo = ok ? (unsigned)row * wb + (unsigned)col * 4u : OOB;
+            unsigned so = (unsigned)(wvu >> 1) * pl4;
 #pragma unroll
-        for (int bi = 0; bi < XB; ++bi) {
-            const int pr = wvu + 4 * bi;
-            const int ch = pr / BRB, r = pr - ch * BRB, row = row0 + r;
-            const bool ok = pr < nxr && row < h1;
-            const unsigned so = ok ? (unsigned)((((size_t)n * K + ch) * plane + (size_t)row * g.W) * 4) : OOB;
-            xv[bi] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx_, (int)(so + vx), 0, 0));
-            xe[bi] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx_, (int)(so + ve), 0, 0));
-        }
-#pragma unroll
-        for (int bi = 0; bi < YB; ++bi) {
-            const int pr = wvu + 4 * bi;
-            const int ch = pr / RBY, r = pr - ch * RBY, row = row0 - PAD + r;
-            const bool ok = pr < nyr && row >= h0 && row < h1;
-            const unsigned so = ok ? (unsigned)((((size_t)n * K + ch) * plane + (size_t)row * g.W) * 4) : OOB;
-            yv[bi] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry_, (int)(so + vy), 0, 0));
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int bi = 0; bi < XB; ++bi) {
-            const int pr = wv + 4 * bi;
-            if (pr < nxr) {
-                const int ch = pr / BRB, r = pr - ch * BRB;
-                unsigned short* d = Xr + ((size_t)ch * BRB + r) * BXW + lane;
-                split_store(xv[bi], d, NP == 2 ? d + xPlane : nullptr);
-                if (lane < 16) split_store(xe[bi], d + 64, NP == 2 ? d + 64 + xPlane : nullptr);
+            for (int bi = 0; bi < XB; ++bi) {
+                xv[bi] = ld2(rx_, vo, so);
+                so += 4 * pl4;
             }
         }
 #pragma unroll
-        for (int bi = 0; bi < YB; ++bi) {
-            const int pr = wv + 4 * bi;
-            if (pr < nyr) {
-                const int ch = pr / RBY, r = pr - ch * RBY;
-                unsigned short* d = Ys + ((size_t)ch * RBY + r) * BYW + lane;
-                split_store(yv[bi], d, NP == 2 ? d + yPlane : nullptr);
+        for (int e = 0; e < XE; ++e) {      // X extra: pr = 8E + (lane >> 3): ch = 2E + (lane >> 5), r = (lane >> 3) & 3; px 64 + 2*(lane & 7)
+            const int E = wvu + 8 * e, ch = 2 * E + half, r = (lane >> 3) & 3, row = row0 + r, col = col0 + 56 + 2 * (lane & 7);
+            const bool ok = E < 10 && ch < K && row < h1 && col + 1 >= w0 && col < w1;
+            const unsigned vo = ok ? (unsigned)ch * pl4 + (unsigned)row * wb + (unsigned)col * 4u : OOB;
+            xe[e] = ld2(rx_, vo, 0);
+        }
+        {   // Y: U = wvu + 8*bi, bi = YPER*u + v: channel c_v + YCST*u, row pair q_v
+            const int col = col0 + 2 * l31;
+            const unsigned vc = col < w1 ? (unsigned)col * 4u : OOB;
+#pragma unroll
+            for (int v = 0; v < YPER; ++v) {
+                const int U = wvu + 8 * v, ch = U / YH, r = 2 * (U - ch * YH) + half, row = row0 - PAD + r;
+                const unsigned vo = (vc != OOB && row >= h0 && row < h1) ? (unsigned)row * wb + vc : OOB;
+                unsigned so = (unsigned)ch * pl4;
+#pragma unroll
+                for (int u = 0; u * YPER + v < YB; ++u) {
+                    yv[u * YPER + v] = ld2(ry_, vo, so);
+                    so += YCST * pl4;
+                }
+            }
+        }
+    };
+    // split a pixel pair into packed (hi, hi) and (lo, lo) bf16 words
+    auto store2 = [&](f32x2 v, bool k0, bool k1, unsigned short* d, size_t planeStride) {
+        const float a = k0 ? v[0] : 0.f, b = k1 ? v[1] : 0.f;
+        const unsigned short ha = f32_to_bf16_bits(a), hb = f32_to_bf16_bits(b);
+        *reinterpret_cast<unsigned*>(d) = (unsigned)ha | ((unsigned)hb << 16);
+        if (NP == 2)
+            *reinterpret_cast<unsigned*>(d + planeStride) = (unsigned)f32_to_bf16_bits(a - bf16_bits_to_f32(ha)) |
+                                                            ((unsigned)f32_to_bf16_bits(b - bf16_bits_to_f32(hb)) << 16);
+    };
+    auto commit = [&]() {
+        {
+            const int r = 2 * (wvu & 1) + half, col = pcol0 - 8 + 2 * l31;
+            const bool k0 = col >= w0 && col < w1, k1 = col + 1 >= w0 && col + 1 < w1;
+#pragma unroll
+            for (int bi = 0; bi < XB; ++bi) {
+                const int ch = (wvu >> 1) + 4 * bi;
+                if (ch < K) store2(xv[bi], k0, k1, Xr + ((size_t)ch * BRB + r) * BXW + 2 * l31, xPlane);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < XE; ++e) {
+            const int E = wvu + 8 * e, ch = 2 * E + half, r = (lane >> 3) & 3, col = pcol0 + 56 + 2 * (lane & 7);
+            const bool k0 = col >= w0 && col < w1, k1 = col + 1 >= w0 && col + 1 < w1;
+            if (E < 10 && ch < K) store2(xe[e], k0, k1, Xr + ((size_t)ch * BRB + r) * BXW + 64 + 2 * (lane & 7), xPlane);
+        }
+        {
+            const int col = pcol0 + 2 * l31;
+            const bool k0 = col < w1, k1 = col + 1 < w1;
+#pragma unroll
+            for (int bi = 0; bi < YB; ++bi) {
+                const int u = bi / YPER, v = bi % YPER;
+                const int U = wvu + 8 * v, c0 = U / YH, r = 2 * (U - c0 * YH) + half, ch = c0 + YCST * u;
+                if (ch < K) store2(yv[bi], k0, k1, Ys + ((size_t)ch * RBY + r) * BYW + 2 * l31, yPlane);
             }
         }
     };
@@ -146,7 +207,7 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
         for (int step = 0; step < (BRB / 2) * (BKW / 32); ++step) {
             const int rx = pair + 2 * (step / (BKW / 32)), ks = step % (BKW / 32);
             // ---- materialise the T shifted copies of row rx, pixels [32ks, 32ks+32): As[pl][dx][i][k] = Xr[pl][i][rx][8+32ks+k+dx-PAD]
-            for (int task = ptid; task < NP * K * 4; task += 128) {
+            for (int task = ptid; task < NP * K * 4; task += 256) {
                 const int c8 = task & 3, i = (task >> 2) % K, pl = task / (4 * K);
                 const unsigned* wsrc = reinterpret_cast<const unsigned*>(Xr + pl * xPlane + ((size_t)i * BRB + rx) * BXW + 32 * ks + 8 * c8);
                 unsigned dwin[12];
@@ -175,14 +236,14 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    if (TS::row_used(mt)) af[pl][mt] = *reinterpret_cast<const bf16x8_t*>(As + pl * aPlane + aoff[mt]);
+                    if (TS::row_used(mt)) af[pl][mt] = *reinterpret_cast<const bf16x8_t*>(As + pl * aPlane + aoff(mt));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (TS::col_used(nt) && nt < ntu) {
                     bf16x8_t bfr[NP];
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
-                        bfr[pl] = *reinterpret_cast<const bf16x8_t*>(Ys + pl * yPlane + boff[nt] + rx * BYW + 32 * ks);
+                        bfr[pl] = *reinterpret_cast<const bf16x8_t*>(Ys + pl * yPlane + boff(nt) + rx * BYW + 32 * ks);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         if (TS::mine(mt, nt) && mt < mtu) {
@@ -228,8 +289,12 @@ __global__ __launch_bounds__(kBT, 1) void joint_fwd_bf16_kernel(const float* __r
                                                                   const float* __restrict__ mask, JointGeom g,
                                                                   const int32_t* __restrict__ win, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) joint_bf16_body<MT, NT, PAD, NTERMS, 1>(x, y, mask, g, win, partials, ldsb);
-    else joint_bf16_body<MT, NT, PAD, NTERMS, 0>(x, y, mask, g, win, partials, ldsb);
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {
+        case 0: joint_bf16_body<MT, NT, PAD, NTERMS, 0>(x, y, mask, g, win, partials, ldsb); break;
+        case 1: joint_bf16_body<MT, NT, PAD, NTERMS, 1>(x, y, mask, g, win, partials, ldsb); break;
+        case 2: joint_bf16_body<MT, NT, PAD, NTERMS, 2>(x, y, mask, g, win, partials, ldsb); break;
+        default: joint_bf16_body<MT, NT, PAD, NTERMS, 3>(x, y, mask, g, win, partials, ldsb); break;
+    }
 }
 
 static size_t bf16_lds_bytes(const JointGeom& g, int nterms) {
@@ -244,7 +309,7 @@ bool joint_fwd_bf16_supported(const JointGeom& g) {
     if (g.sb != 1) return false;
     if (!((g.pad == 3 && g.tilesM > 4 && g.tilesM <= 9) || (g.pad == 1 && g.tilesM <= 4))) return false;
     if ((size_t)g.N * g.K * g.H * g.W * 4 >= 0x40000000ull) return false;   // 32-bit buffer offsets with an out-of-range marker
-    if (g.K * BRB > 80 || g.K * (BRB + 2 * g.pad) > 200) return false;   // prefetch register batches (XB, YB rows per wave)
+    if (g.K * BRB > 80 || g.K * (BRB + 2 * g.pad) > 200) return false;   // prefetch register batches (XB, YB rows per wave, 8 waves)
     return bf16_lds_bytes(g, 3) <= (size_t)kLdsBudget;
 }
 
