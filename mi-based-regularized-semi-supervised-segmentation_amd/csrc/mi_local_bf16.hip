@@ -50,7 +50,33 @@ struct QuadTiles {
             if (mine(m, n)) return true;
         return false;
     }
+    static constexpr int first_col() {
+        for (int n = 0; n < NT; ++n)
+            if (col_used(n)) return n;
+        return 0;
+    }
+    static constexpr int next_col(int n) {      // next used column after n, NT if none
+        for (int k = n + 1; k < NT; ++k)
+            if (col_used(k)) return k;
+        return NT;
+    }
+    static constexpr int nth_col(int j) {       // j-th used column, NT if there are fewer
+        int r = 0;
+        for (int k = 0; k < NT; ++k)
+            if (col_used(k)) {
+                if (r == j) return k;
+                ++r;
+            }
+        return NT;
+    }
+    static constexpr int col_rank(int n) {      // how many used columns precede n
+        int r = 0;
+        for (int k = 0; k < n; ++k) r += col_used(k) ? 1 : 0;
+        return r;
+    }
 };
+
+template <int PAD> constexpr int T_of() { return 2 * PAD + 1; }
 
 template <int MT, int NT, int PAD, int NTERMS, int ROLE>
 __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mask,
@@ -58,15 +84,15 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
                                                 unsigned char* lds) {
     typedef QuadTiles<MT, NT, ROLE> TS;
     constexpr int T = 2 * PAD + 1, NP = NTERMS == 1 ? 1 : 2, RBY = BRB + 2 * PAD;
-    const int K = g.K;
+    constexpr int K = 20;                                  // the shipped cluster count (host check): divisions by K fold to multiplies
     // LDS carve (bf16 = unsigned short)
     unsigned short* Xr = reinterpret_cast<unsigned short*>(lds);                 // [NP][K][BRB][BXW]
     unsigned short* Ys = Xr + (size_t)NP * K * BRB * BXW;                        // [NP][K][RBY][BYW]
-    unsigned short* Asb = Ys + (size_t)NP * K * RBY * BYW;                       // [2 quads][NP][T][K][BAW]
+    unsigned short* Asb = Ys + (size_t)NP * K * RBY * BYW;                       // [2 quads][2 buffers][NP][T][K][BAW]
     const size_t xPlane = (size_t)K * BRB * BXW, yPlane = (size_t)K * RBY * BYW, aPlane = (size_t)T * K * BAW;
     const int tid = threadIdx.x, lane = tid & 63, pair = tid >> 8, ptid = tid & 255, wv = tid >> 6;   // pair = quad index
     const int l15 = lane & 15, q = lane >> 4;
-    unsigned short* As = Asb + (size_t)pair * NP * aPlane;
+    unsigned short* As = Asb + (size_t)pair * 2 * NP * aPlane;                   // this quad's two buffers
 
     const int slot = blockIdx.y;                          // one sub-block only on this path (T*K <= 144): slot = sub-head * P + window
     const int shead = slot / g.P, p = slot - shead * g.P;
@@ -75,7 +101,7 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
     const int h0 = win[p * 4 + 0], h1 = win[p * 4 + 1], w0 = win[p * 4 + 2], w1 = win[p * 4 + 3];
     const int tr = (h1 - h0 + BRB - 1) / BRB, tc = (w1 - w0 + BKW - 1) / BKW;
     const int nItems = g.N * tr * tc;
-    const int mtu = g.tilesM, ntu = g.tilesM;
+    static_assert(MT == (T_of<PAD>() * 20 + 15) / 16 && NT == MT, "tile counts are tied to K = 20");
 
     auto aoff = [&](int mt) {                             // m = dx*K + i is exactly the As row index; swizzled 16-B slot
         const int m = min(mt * 16 + l15, g.Mdim - 1);
@@ -203,10 +229,12 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
         commit();
         __syncthreads();
         if (it + g.G < nItems) prefetch(it + g.G);   // in flight during the MFMA phases below
-#pragma unroll 1
-        for (int step = 0; step < (BRB / 2) * (BKW / 32); ++step) {
+        // ---- materialise the T shifted copies of row rx, pixels [32ks, 32ks+32) into As buffer `buf`:
+        //      As[pl][dx][i][k] = Xr[pl][i][rx][8+32ks+k+dx-PAD]
+        constexpr int NSTEP = (BRB / 2) * (BKW / 32);
+        auto materialise = [&](int step, int buf) {
             const int rx = pair + 2 * (step / (BKW / 32)), ks = step % (BKW / 32);
-            // ---- materialise the T shifted copies of row rx, pixels [32ks, 32ks+32): As[pl][dx][i][k] = Xr[pl][i][rx][8+32ks+k+dx-PAD]
+            unsigned short* Ab = As + (size_t)buf * NP * aPlane;
             for (int task = ptid; task < NP * K * 4; task += 256) {
                 const int c8 = task & 3, i = (task >> 2) % K, pl = task / (4 * K);
                 const unsigned* wsrc = reinterpret_cast<const unsigned*>(Xr + pl * xPlane + ((size_t)i * BRB + rx) * BXW + 32 * ks + 8 * c8);
@@ -227,36 +255,61 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
                         o[t] = (s & 1) ? __builtin_amdgcn_alignbit(dwin[d0 + 1], dwin[d0], 16) : dwin[d0];
                     }
                     const int m = dx * K + i;
-                    *reinterpret_cast<u32x4*>(As + pl * aPlane + (size_t)m * BAW + 8 * (c8 ^ ((m >> 2) & 3))) = o;
+                    *reinterpret_cast<u32x4*>(Ab + pl * aPlane + (size_t)m * BAW + 8 * (c8 ^ ((m >> 2) & 3))) = o;
                 }
             }
-            __syncthreads();
+        };
+        // As is double-buffered: step s multiplies out of buffer s & 1 while the copies for step s+1 are written into the other
+        // one -- by quad 0 BEFORE its MFMAs and by quad 1 AFTER them.  A SIMD hosts one wave of each quad, so in each half of a
+        // step one of its waves is on the matrix pipe and the other on the LDS; one barrier per step.
+        materialise(0, 0);
+        __syncthreads();
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; ++step) {
+            const int rx = pair + 2 * (step / (BKW / 32)), ks = step % (BKW / 32);
+            const unsigned short* Ab = As + (size_t)(step & 1) * NP * aPlane;
+            if (pair == 0 && step + 1 < NSTEP) materialise(step + 1, (step + 1) & 1);
             bf16x8_t af[NP][MT];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    if (TS::row_used(mt)) af[pl][mt] = *reinterpret_cast<const bf16x8_t*>(As + pl * aPlane + aoff(mt));
+                    if (TS::row_used(mt)) af[pl][mt] = *reinterpret_cast<const bf16x8_t*>(Ab + pl * aPlane + aoff(mt));
+            // B fragments one tile column ahead of the MFMAs (two register slots): a column's 2-3 accumulator tiles are only
+            // ~100 cycles of matrix work, less than an LDS read's latency.
+            constexpr int BQ = NTERMS == 3 ? 2 : 4;                           // register slots: BQ - 1 columns in flight (x3: register budget)
+            bf16x8_t bq[BQ][NP];
+            auto load_b = [&](int nt, bf16x8_t* dst) {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    dst[pl] = *reinterpret_cast<const bf16x8_t*>(Ys + pl * yPlane + boff(nt) + rx * BYW + 32 * ks);
+            };
+#pragma unroll
+            for (int j = 0; j < BQ - 1; ++j)
+                if (TS::nth_col(j) < NT) load_b(TS::nth_col(j), bq[j]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (TS::col_used(nt) && nt < ntu) {
-                    bf16x8_t bfr[NP];
+                if (TS::col_used(nt)) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int rank = TS::col_rank(nt), slot = rank % BQ;       // compile-time after unrolling
+                    if (TS::nth_col(rank + BQ - 1) < NT) load_b(TS::nth_col(rank + BQ - 1), bq[(rank + BQ - 1) % BQ]);
+                    __builtin_amdgcn_sched_barrier(0);     // or the scheduler sinks the read next to its use
+                    {   // MT = NT = ceil(T*K/16) exactly (K compile-time, checked on the host): no runtime tile guards -> straight-line MFMAs
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        bfr[pl] = *reinterpret_cast<const bf16x8_t*>(Ys + pl * yPlane + boff(nt) + rx * BYW + 32 * ks);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        if (TS::mine(mt, nt) && mt < mtu) {
-                            if (NTERMS == 3) {
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1][mt], bfr[0], acc[mt][nt], 0, 0, 0);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], bfr[NP - 1], acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (TS::mine(mt, nt)) {
+                                if (NTERMS == 3) {
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1][mt], bq[slot][0], acc[mt][nt], 0, 0, 0);
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], bq[slot][NP - 1], acc[mt][nt], 0, 0, 0);
+                                }
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], bq[slot][0], acc[mt][nt], 0, 0, 0);
                             }
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], bfr[0], acc[mt][nt], 0, 0, 0);
                         }
                     }
                 }
             }
-            __syncthreads();   // As is rewritten by the next step
+            if (pair == 1 && step + 1 < NSTEP) materialise(step + 1, (step + 1) & 1);
+            __syncthreads();   // step s+1's copies complete; buffer s & 1 free for step s+2
         }
     }
     // ---- reduce the 2 pairs' accumulators through LDS in fixed order, then one partial per block
@@ -299,14 +352,14 @@ __global__ __launch_bounds__(kBT, 1) void joint_fwd_bf16_kernel(const float* __r
 
 static size_t bf16_lds_bytes(const JointGeom& g, int nterms) {
     const int np = nterms == 1 ? 1 : 2, T = g.T, rby = BRB + 2 * g.pad;
-    const size_t tiles = ((size_t)np * g.K * BRB * BXW + (size_t)np * g.K * rby * BYW + (size_t)2 * np * T * g.K * BAW) * 2;
+    const size_t tiles = ((size_t)np * g.K * BRB * BXW + (size_t)np * g.K * rby * BYW + (size_t)2 * 2 * np * T * g.K * BAW) * 2;
     const int cap = g.tilesM <= 4 ? 4 : 9;
     const size_t dred = (size_t)(cap * 16) * (cap * 16) * 4;
     return tiles > dred ? tiles : dred;
 }
 
 bool joint_fwd_bf16_supported(const JointGeom& g) {
-    if (g.sb != 1) return false;
+    if (g.sb != 1 || g.K != 20) return false;
     if (!((g.pad == 3 && g.tilesM > 4 && g.tilesM <= 9) || (g.pad == 1 && g.tilesM <= 4))) return false;
     if ((size_t)g.N * g.K * g.H * g.W * 4 >= 0x40000000ull) return false;   // 32-bit buffer offsets with an out-of-range marker
     if (g.K * BRB > 80 || g.K * (BRB + 2 * g.pad) > 200) return false;   // prefetch register batches (XB, YB rows per wave, 8 waves)
