@@ -252,7 +252,7 @@ class TrainEpocher(_num_class_mixin, _Epocher):
                 predict_logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
             finally:
                 self._after_forward()
-        label_logits, unlabel_logits, unlabel_tf_logits = torch.split(predict_logits, [lb, ub, ub], dim=0)
+        label_logits, unlabel_logits, unlabel_tf_logits = ops.split_rows(predict_logits, [lb, ub, ub])
         labels = labeled_target.squeeze(1)
         with checks.deferred(self._pending.checks):
             if isinstance(self._sup_criterion, KL_div) and self._sup_criterion.supports_fused():
