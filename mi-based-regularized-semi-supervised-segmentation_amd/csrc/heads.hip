@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_kernel(const T* __restrict
 // pixel and no LDS traffic at all (the LDS-column kernel above spends ~15 LDS operations per logit update).
 // Logits accumulate through explicit FMAs (channel order) and the softmax multiplies by one reciprocal per pixel: results
 // differ from head_local_fwd_kernel by an ulp or two, inside the parity tolerance of tests/test_gpu_mi.py.
-template <typename T, int KP, int PPT>
+template <typename T, int KP, int PPT, bool EXACT>   // EXACT: K == KP, no per-class guards (K = 20 ships)
 __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __restrict__ feat, int H, int W, int C,
                                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                  int M, const float* __restrict__ w, const float* __restrict__ b, int S,
@@ -74,6 +74,12 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
     const int pix0 = (blockIdx.x * kHT + tid) * PPT;
     const bool live = pix0 < HW;
     const int f = flips ? flips[m] : 0;
+    // all S*K*C weights staged once per block; the inner loop reads them as broadcast ds_read_b128 (every lane the same
+    // address), which the compiler keeps a dozen deep in flight -- as scalar loads each batch of weights was a serial
+    // scalar-cache round trip in front of its FMAs
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    for (int i = tid; i < S * K * C; i += kHT) wl[i] = w[i];
+    __syncthreads();
     const T* fp[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -82,11 +88,11 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
     }
     int nbad = 0;
     for (int s = 0; s < S; ++s) {
-        const float* ws = w + (size_t)s * K * C;
+        const float* ws = wl + (size_t)s * K * C;
         float z[PPT][KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const float bv = b[s * K + min(k, K - 1)];
+            const float bv = b[s * K + (EXACT ? k : min(k, K - 1))];
 #pragma unroll
             for (int j = 0; j < PPT; ++j) z[j][k] = bv;
         }
@@ -100,32 +106,34 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
             }
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const float* wr = ws + (size_t)min(k, K - 1) * C + c0;
-                const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+                const float4 wq4 = *reinterpret_cast<const float4*>(ws + (size_t)(EXACT ? k : min(k, K - 1)) * C + c0);
+                const float w0 = wq4.x, w1 = wq4.y, w2 = wq4.z, w3 = wq4.w;
 #pragma unroll
                 for (int j = 0; j < PPT; ++j) z[j][k] = fmaf(w3, fr[j][3], fmaf(w2, fr[j][2], fmaf(w1, fr[j][1], fmaf(w0, fr[j][0], z[j][k]))));
             }
         }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
+            // softmax(z / T): exp((z - max) / T) as ONE fma + v_exp_f32 (exp2 of a pre-scaled argument).  The library expf spends
+            // ~12 instructions per value on range handling this argument (<= 0, finite) never needs -- it was 40 % of the kernel's
+            // instructions -- and v_exp_f32 is accurate to ~1 ulp, inside the 1e-5 parity bound on the probabilities.
             float mx = -3.4e38f;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                z[j][k] *= invT;
-                if (k < K) mx = fmaxf(mx, z[j][k]);
-            }
+            for (int k = 0; k < KP; ++k)
+                if (EXACT || k < K) mx = fmaxf(mx, z[j][k]);
+            const float sc2 = invT * 1.4426950408889634f, off2 = -mx * sc2;
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                z[j][k] = expf(z[j][k] - mx);
-                if (k < K) sum += z[j][k];
+                z[j][k] = __builtin_amdgcn_exp2f(fmaf(z[j][k], sc2, off2));
+                if (EXACT || k < K) sum += z[j][k];
             }
             const float inv = 1.0f / sum;
             float ps = 0.f;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 z[j][k] *= inv;
-                if (k < K) ps += z[j][k];
+                if (EXACT || k < K) ps += z[j][k];
             }
             nbad += !(fabsf(ps - 1.f) <= tol);   // the caller's simplex assertion, evaluated while the values are in registers
         }
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
             float* out = prob + (((size_t)s * M + m) * K) * HW + pix0;
 #pragma unroll
             for (int k = 0; k < KP; ++k)
-                if (k < K) {
+                if (EXACT || k < K) {
                     if (PPT == 4) *reinterpret_cast<float4*>(out + (size_t)k * HW) = make_float4(z[0][k], z[1][k], z[2][k], z[3][k]);
                     else out[(size_t)k * HW] = z[0][k];
                 }
@@ -491,8 +499,9 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
         const dim3 gridq((unsigned)cdiv(H * W, kHT * 4), (unsigned)M);
 #define HLF(TT, KPP)                                                                                                                   \
     {                                                                                                                                 \
-        if (quad) hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 4>), gridq, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
-        else hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 1>), grid, dim3(kHT), 0, st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
+        if (quad && K == KPP) hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 4, true>), gridq, dim3(kHT), (size_t)(S * K * C * 4), st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
+        else if (quad) hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 4, false>), gridq, dim3(kHT), (size_t)(S * K * C * 4), st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
+        else hipLaunchKernelGGL((head_local_fwd_reg_kernel<TT, KPP, 1, false>), grid, dim3(kHT), (size_t)(S * K * C * 4), st, (const TT*)feat, (int)H, (int)W, (int)C, src, flips, (int)M, w, b, (int)S, (int)K, 1.0f / T, prob, simplex_tol, simplex_violations); \
     }
 #define HLF_K(TT) switch ((K + 3) / 4) { case 1: HLF(TT, 4); break; case 2: HLF(TT, 8); break; case 3: HLF(TT, 12); break; case 4: HLF(TT, 16); break; \
                                          case 5: HLF(TT, 20); break; case 6: HLF(TT, 24); break; case 7: HLF(TT, 28); break; default: HLF(TT, 32); break; }
