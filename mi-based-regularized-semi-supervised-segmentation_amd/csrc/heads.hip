@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restri
 //   phase 2 (fp32 MFMA):       gfeat[px][c] = sum_(s,k) dz[(s,k)][px] * W[(s,k)][c]     (M=px, N=c, Kred=S*K)
 //   phase 3 (fp32 MFMA):       gw[(s,k)][c] += sum_px dz[(s,k)][px] * f[px][c]          (M=(s,k), N=c, Kred=px)
 // gw / gb accumulate in registers across the block's chunks; one deterministic partial per block at the end.
-template <typename T, int CTM, int RW>
+template <typename T, int CTM, int RW, bool K20>   // K20: K == 20 and S*K <= 100 -> a row's sub-head is i / 5, a compile-time index
 __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                    int M, const float* __restrict__ w, int S, int K, float invT,
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
     float* dzs = sm;                          // [RP][DZS]   p*g, then dz; rows >= R zero
     float* fs = dzs + (size_t)RP * DZS;       // [64][FS]    feature chunk (fp32)
     float* wsm = fs + (size_t)64 * FS;        // [RP][WS]    head weights, rows >= R zero
-    float* dots = wsm + (size_t)RP * WS;      // [S][64]     <g,p> per (sub-head, pixel)
+    float* dots = wsm + (size_t)RP * WS;      // [4 waves][S][64]  partial <g,p> per (wave, sub-head, pixel); generic path: [S][64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     for (int idx = tid; idx < RP * C; idx += 256) {
         const int c = idx % C, r = idx / C;
@@ -321,6 +321,12 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
 #pragma unroll
         for (int c = 0; c < CTM; ++c) accw[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float gbacc = 0.f;
+    float gbr[K20 ? 25 : 1];                  // K20: per-lane partial sums of dz per owned row, reduced across the wave at the end
+#pragma unroll
+    for (int i = 0; i < (K20 ? 25 : 1); ++i) gbr[i] = 0.f;
+    int fq[FPT], fc[FPT];                     // chunk-invariant (pixel, channel) of this thread's feature slots
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) { const int idx = tid + 256 * j; fq[j] = idx / C; fc[j] = idx - fq[j] * C; }
     const int chunksPerM = (HW + 63) / 64;
     const int64_t nchunks = (int64_t)M * chunksPerM;
     const uint32_t kmagic = (65536u + (uint32_t)K - 1u) / (uint32_t)K;   // r / K == (r * kmagic) >> 16 for r*K < 65536
@@ -328,13 +334,17 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
     // Rows r = wv + 4i of (s,k) belong to wave wv: every wave streams ~R/4 coalesced 256-byte row segments of prob and
     // gprob per chunk.  The chunk's values live in registers and are fetched one chunk ahead (issued before the MFMA
     // phases of the current chunk), so the HBM latency hides behind phases 2/3.
-    float pr[RW], gr[RW], fr[FPT];
+    // NOTHING in fetch() may read a loaded value: a select or a conversion right after the load makes the compiler wait for it,
+    // and 50 loads then cost 50 serial memory latencies (measured: 28 k of a chunk's 52 k cycles).  Dead pixels get an
+    // out-of-range buffer offset (the hardware returns 0); features stay raw T until phase 1.
+    float pr[RW], gr[RW];
+    T fr[FPT];
     const int wvu = __builtin_amdgcn_readfirstlane(wv);   // wave-uniform: row offsets below stay in SGPRs
     const size_t tot = (size_t)S * M * K * HW;            // floats in prob / gprob (host checks tot*4 < 2^32)
     auto fetch = [&](int64_t ch) {
         const int m = ch / chunksPerM, p0 = (ch % chunksPerM) * 64;
         const bool live = p0 + px < HW;
-        const int pxc = live ? px : 0;
+        const int voff = live ? px * 4 : (int)0x80000000;   // past num_records for any chunk
         // one buffer resource per chunk (uniform base), row offsets as scalar soffsets, px as the only VGPR offset
         const size_t boff = (size_t)m * K * HW + p0;
         const uint32_t rem = (uint32_t)((tot - boff) * 4);
@@ -345,22 +355,17 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
             const int r = min(wvu + 4 * i, R - 1);   // rows past R re-read row R-1 (branch-free issue); never stored
             const int sidx = (int)(((uint32_t)r * kmagic) >> 16);
             const uint32_t so = ((uint32_t)r + (uint32_t)sidx * (uint32_t)(M - 1) * (uint32_t)K) * (uint32_t)HW * 4u;
-            const float pv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, pxc * 4, (int)so, 0));
-            const float gv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, pxc * 4, (int)so, 0));
-            pr[i] = live ? pv : 0.f;
-            gr[i] = live ? gv : 0.f;
+            pr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, voff, (int)so, 0));
+            gr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, voff, (int)so, 0));
         }
         const int f = flips ? flips[m] : 0;
         const size_t fb = (size_t)src[m] * HW;
 #pragma unroll
         for (int j = 0; j < FPT; ++j) {
-            const int idx = tid + 256 * j, c = idx % C, q = idx / C;
-            float v = 0.f;
-            if (idx < 64 * C && p0 + q < HW) {
-                const int pq = p0 + q, h = pq / W, wq = pq % W;
-                v = to_f32(feat[(fb + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c]);
-            }
-            fr[j] = v;
+            const int idx = tid + 256 * j, c = fc[j], q = fq[j];
+            const bool ok = idx < 64 * C && p0 + q < HW;
+            const int pq = ok ? p0 + q : 0, h = pq / W, wq = pq - h * W;
+            fr[j] = feat[ok ? (fb + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c : 0];   // dead slots re-read element 0; masked at use
         }
     };
     if ((int64_t)blockIdx.x < nchunks) fetch(blockIdx.x);
@@ -369,37 +374,63 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
         const int f = flips ? flips[m] : 0;
         __syncthreads();   // previous chunk's MFMA phases are done with dzs / fs
         // ---- phase 1: dz = p*(g - <g,p>)/T
+        if (K20) {
+            // <g,p> per sub-head from the wave's own registers: rows r = wv + 4i, sub-head i / 5 (5 rows of each sub-head per
+            // wave); the four waves' partials meet in LDS.  No p*g round trip through LDS, the work is the same on every wave.
+            float part[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const int r = wvu + 4 * i;
-            if (r < R) dzs[r * DZS + px] = pr[i] * gr[i];
+            for (int i = 0; i < 25; ++i) part[i / 5] = fmaf(pr[i], gr[i], part[i / 5]);
+#pragma unroll
+            for (int sh = 0; sh < 5; ++sh) dots[(wvu * 5 + sh) * 64 + px] = part[sh];
+        } else {
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const int r = wvu + 4 * i;
+                if (r < R) dzs[r * DZS + px] = pr[i] * gr[i];
+            }
         }
 #pragma unroll
-        for (int j = 0; j < FPT; ++j) {
-            const int idx = tid + 256 * j;
-            if (idx < 64 * C) fs[(idx / C) * FS + idx % C] = fr[j];
-        }
+        for (int j = 0; j < FPT; ++j)
+            if (tid + 256 * j < 64 * C) fs[fq[j] * FS + fc[j]] = (p0 + fq[j] < HW) ? to_f32(fr[j]) : 0.f;
         __syncthreads();
-        for (int sidx = wv; sidx < S; sidx += 4) {
-            float dot = 0.f;
+        if (K20) {
+            float dot[5];
+#pragma unroll
+            for (int sh = 0; sh < 5; ++sh)
+                dot[sh] = (sh < S) ? ((dots[(0 * 5 + sh) * 64 + px] + dots[(1 * 5 + sh) * 64 + px]) + (dots[(2 * 5 + sh) * 64 + px] + dots[(3 * 5 + sh) * 64 + px])) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 25; ++i) {
+                const int r = wvu + 4 * i;
+                const float dz = pr[i] * (gr[i] - dot[i / 5]) * invT;
+                if (r < R) {
+                    dzs[r * DZS + px] = dz;
+                    gbr[i] += dz;
+                }
+            }
+            if (ch + nblk < nchunks) fetch(ch + nblk);
+            __syncthreads();
+        } else {
+            for (int sidx = wv; sidx < S; sidx += 4) {
+                float dot = 0.f;
 #pragma unroll 4
-            for (int k = 0; k < K; ++k) dot += dzs[(sidx * K + k) * DZS + px];
-            dots[sidx * 64 + px] = dot;
-        }
-        __syncthreads();
+                for (int k = 0; k < K; ++k) dot += dzs[(sidx * K + k) * DZS + px];
+                dots[sidx * 64 + px] = dot;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const int r = wvu + 4 * i;
-            const int sidx = (int)(((uint32_t)r * kmagic) >> 16);
-            if (r < R) dzs[r * DZS + px] = pr[i] * (gr[i] - dots[sidx * 64 + px]) * invT;
-        }
-        if (ch + nblk < nchunks) fetch(ch + nblk);
-        __syncthreads();
-        if (tid < R) {
-            float a = 0.f;
+            for (int i = 0; i < RW; ++i) {
+                const int r = wvu + 4 * i;
+                const int sidx = (int)(((uint32_t)r * kmagic) >> 16);
+                if (r < R) dzs[r * DZS + px] = pr[i] * (gr[i] - dots[sidx * 64 + px]) * invT;
+            }
+            if (ch + nblk < nchunks) fetch(ch + nblk);
+            __syncthreads();
+            if (tid < R) {
+                float a = 0.f;
 #pragma unroll 8
-            for (int q = 0; q < 64; ++q) a += dzs[tid * DZS + q];
-            gbacc += a;
+                for (int q = 0; q < 64; ++q) a += dzs[tid * DZS + q];
+                gbacc += a;
+            }
         }
         // ---- phase 2: gfeat tile [64 px][C]: wave wv owns pixel tile wv (16 px).  Operands swapped so that D^T comes out:
         // a lane holds 4 consecutive channels of one pixel -> one 8-byte (bf16) / 16-byte (fp32) store.  Plain stores: every
@@ -408,7 +439,7 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
             f32x4 accf[CTM];
 #pragma unroll
             for (int c = 0; c < CTM; ++c) accf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 7
             for (int ks = 0; ks < RP; ks += 4) {
                 const float av = dzs[(ks + kq) * DZS + wv * 16 + l15];
 #pragma unroll
@@ -441,7 +472,7 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
             }
         }
         // ---- phase 3: gw += dz * f
-#pragma unroll 2
+#pragma unroll 4
         for (int ks = 0; ks < 64; ks += 4) {
             float bfr[CTM];
 #pragma unroll
@@ -474,7 +505,13 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
                 }
         }
     }
-    if (tid < R) out[R * C + tid] = gbacc;
+    if (K20) {
+#pragma unroll
+        for (int i = 0; i < 25; ++i) {
+            const float v = wave_sum(gbr[i]);
+            if (lane == 0 && wvu + 4 * i < R) out[R * C + wvu + 4 * i] = v;
+        }
+    } else if (tid < R) out[R * C + tid] = gbacc;
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ out) {
@@ -538,15 +575,15 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     hipStream_t st = as_stream(stream);
     float* partials = (float*)ws;
     const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16, RP = RT * 16;
-    const size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1) + (size_t)S * 64) * 4;
+    const size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1) + (size_t)4 * std::max<int64_t>(S, 5) * 64) * 4;
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
-#define HLB2(TT, CTM, RW)                                                                                                         \
+#define HLB2(TT, CTM, RW, K20V)                                                                                                         \
     {                                                                                                                             \
-        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
+        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW, K20V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW, K20V>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
                            src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);            \
     }
-#define HLB(TT, CTM) { if (R <= 112) HLB2(TT, CTM, 28) else HLB2(TT, CTM, 64) }
+#define HLB(TT, CTM) { if (K == 20 && R <= 100) HLB2(TT, CTM, 28, true) else if (R <= 112) HLB2(TT, CTM, 28, false) else HLB2(TT, CTM, 64, false) }
 #define HLB_C(TT) { if (C <= 16) HLB(TT, 1) else if (C <= 32) HLB(TT, 2) else if (C <= 64) HLB(TT, 4) else HLB(TT, 8) }
     if (dt == MISEG_F32) HLB_C(float)
     else if (dt == MISEG_BF16) HLB_C(bf16)
