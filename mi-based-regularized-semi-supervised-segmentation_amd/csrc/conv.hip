@@ -776,16 +776,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <typename T, int CI, int CO>
 __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ in, int64_t npix, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out) {
-    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
-        float f[CI];
+    // the pixel's CI channels arrive as 16-byte vectors and (CO == 4) the logits leave as one float4: per-element 2-byte loads
+    // and 4-byte stores ran this 150 MB stream at 0.9 TB/s
+    float wr[CO * CI], br[CO];
 #pragma unroll
-        for (int c = 0; c < CI; ++c) f[c] = to_f32(in[i * CI + c]);
+    for (int e = 0; e < CO * CI; ++e) wr[e] = w[e];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) br[o] = bias[o];
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        constexpr int NV = CI * (int)sizeof(T) / 16;
+        static_assert(CI * sizeof(T) % 16 == 0, "conv1x1_fwd: the channel vector must be a multiple of 16 bytes");
+        uint4 vin[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vin[v] = reinterpret_cast<const uint4*>(in + i * CI)[v];
+        const T* fe = reinterpret_cast<const T*>(vin);
+        float f[CI], a[CO];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) f[c] = to_f32(fe[c]);
 #pragma unroll
         for (int o = 0; o < CO; ++o) {
-            float a = bias[o];
+            a[o] = br[o];
 #pragma unroll
-            for (int c = 0; c < CI; ++c) a += w[o * CI + c] * f[c];
-            out[i * CO + o] = a;
+            for (int c = 0; c < CI; ++c) a[o] += wr[o * CI + c] * f[c];
+        }
+        if (CO == 4) *reinterpret_cast<float4*>(out + i * 4) = make_float4(a[0], a[1 % CO], a[2 % CO], a[3 % CO]);
+        else {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) out[i * CO + o] = a[o];
         }
     }
 }
@@ -1054,7 +1071,6 @@ extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const flo
     float* red = (float*)ws + (size_t)nb * len;
     hipLaunchKernelGGL(sum_parts2_kernel, dim3(reduce_grid(len, nb)), dim3(256), 0, st, (const float*)ws, nb, len, red);
     MISEG_LAUNCH_CHECK("sum_parts2_kernel");
-    hipMemcpyAsync(gw, red, (size_t)Cout * Cin * 4, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(gbias, red + Cout * Cin, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st);
+    launch_split2(st, red, (int)(Cout * Cin), gw, (int)Cout, gbias);
     return MISEG_OK;
 }

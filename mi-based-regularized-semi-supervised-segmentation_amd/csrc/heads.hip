@@ -596,7 +596,6 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     float* red = partials + (size_t)nblk * len;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(reduce_grid(len, nblk)), dim3(256), 0, st, partials, nblk, len, red);
     MISEG_LAUNCH_CHECK("sum_partials_kernel");
-    hipMemcpyAsync(gw, red, (size_t)R * C * 4, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(gb, red + (size_t)R * C, (size_t)R * 4, hipMemcpyDeviceToDevice, st);
+    launch_split2(st, red, R * (int)C, gw, R, gb);
     return MISEG_OK;
 }

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "miseg_hip.h")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmiseg_hip.so")
+LIB_PATH = os.environ.get("MISEG_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libmiseg_hip.so")   # override: A/B runs of two builds
 
 F32, BF16 = 0, 1
 
