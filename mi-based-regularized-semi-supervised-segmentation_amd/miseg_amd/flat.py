@@ -109,6 +109,9 @@ class FlatBuffers:
         """Make ``flat_grad[offsets[lo]:offsets[hi])`` hold the gradients of params[lo:hi] (see class docstring)."""
         self.ensure()
         hi = len(self.params) if hi is None else hi
+        if self.flat_grad.is_cuda:
+            from .unet_ops import join_wgrad_streams
+            join_wgrad_streams()          # weight gradients are written into the slots from a side stream
         with torch.no_grad():
             for i in range(lo, hi):
                 p, slot = self.params[i], self.slots[i]

@@ -7,6 +7,8 @@ ref: contrastyou/arch/unet.py:10-40 (conv_block / up_conv), :61-64 (pools), :84,
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import struct
@@ -20,6 +22,28 @@ from .gradslot import grad_slot
 from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+# ---- weight gradients off the critical path
+# In the U-Net backward only BN-backward -> dgrad feeds the next layer; a layer's wgrad (+ its split reduction) has no consumer
+# before the optimiser.  It is launched on a side stream so the dgrad chain does not queue behind it and the two fill each
+# other's tails.  Joined before anything reads the flat gradient buffer (FlatBuffers.collect, GradReducer._launch).
+_WGRAD_SIDE = os.environ.get("MISEG_WGRAD_STREAM", "1") != "0"
+_wgrad_streams: dict = {}
+_wgrad_dirty: set = set()
+
+
+def wgrad_stream(device):
+    st = _wgrad_streams.get(device)
+    if st is None:
+        st = _wgrad_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_wgrad_streams() -> None:
+    """Make the current stream wait for every outstanding side-stream wgrad."""
+    for dev in list(_wgrad_dirty):
+        torch.cuda.current_stream(dev).wait_stream(_wgrad_streams[dev])
+    _wgrad_dirty.clear()
 
 
 def vec_of(dtype) -> int:
@@ -195,12 +219,23 @@ class _ConvBNReLU(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[2]:
             gw = grad_slot(pw)
+            side = None
             if gw is None:
                 gw = torch.empty_like(weight)
-            ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
-            call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
-                 _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
-                 tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
+            elif _WGRAD_SIDE and not torch.cuda.is_current_stream_capturing():
+                side = wgrad_stream(dev)      # only when the result lands in the flat buffer: nothing on this stream touches it again
+            cur = torch.cuda.current_stream(dev)
+            if side is not None:
+                side.wait_stream(cur)         # graw is produced above
+                for t in (graw, x0, x1):      # keep their memory from being recycled under the side stream
+                    if t is not None:
+                        t.record_stream(side)
+                _wgrad_dirty.add(dev)
+            with torch.cuda.stream(side if side is not None else cur):
+                ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
+                call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
+                     _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
+                     tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
         grads = [None, None]
         for s, (cb, cs, ups, xs) in enumerate(((0, c0, ups0, x0), (c0, c1, ups1, x1))):
             if xs is None or not ctx.needs_input_grad[s]:
