@@ -28,6 +28,7 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # before the optimiser.  It is launched on a side stream so the dgrad chain does not queue behind it and the two fill each
 # other's tails.  Joined before anything reads the flat gradient buffer (FlatBuffers.collect, GradReducer._launch).
 _WGRAD_SIDE = os.environ.get("MISEG_WGRAD_STREAM", "1") != "0"
+_GRAPH_STREAMS = os.environ.get("MISEG_GRAPH_STREAMS", "1") == "1"   # fork side streams inside a captured step too
 _wgrad_streams: dict = {}
 _wgrad_dirty: set = set()
 
@@ -222,7 +223,7 @@ class _ConvBNReLU(torch.autograd.Function):
             side = None
             if gw is None:
                 gw = torch.empty_like(weight)
-            elif _WGRAD_SIDE and not torch.cuda.is_current_stream_capturing():
+            elif _WGRAD_SIDE and (_GRAPH_STREAMS or not torch.cuda.is_current_stream_capturing()):
                 side = wgrad_stream(dev)      # only when the result lands in the flat buffer: nothing on this stream touches it again
             cur = torch.cuda.current_stream(dev)
             if side is not None:

@@ -372,7 +372,10 @@ class IICTrainEpocher(TrainEpocher):
     # the later decoder blocks.  Backward runs the most recently created chain first, i.e. the last tap -- the one the main
     # stream has to wait for -- goes first.
     def _use_side_stream(self, dev) -> bool:
-        return dev.type == "cuda" and os.environ.get("MISEG_IIC_STREAM", "1") == "1" and not torch.cuda.is_current_stream_capturing()
+        if dev.type != "cuda" or os.environ.get("MISEG_IIC_STREAM", "1") != "1":
+            return False
+        # under hipGraph capture the fork/join (wait_stream both ways) is captured as graph dependencies
+        return os.environ.get("MISEG_GRAPH_STREAMS", "1") == "1" or not torch.cuda.is_current_stream_capturing()
 
     def _side(self, dev):
         side = getattr(self, "_iic_stream", None)
