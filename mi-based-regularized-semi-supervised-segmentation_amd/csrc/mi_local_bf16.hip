@@ -228,7 +228,10 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
         __syncthreads();                 // previous tile fully consumed
         commit();
         __syncthreads();
-        if (it + g.G < nItems) prefetch(it + g.G);   // in flight during the MFMA phases below
+        const bool more_items = it + g.G < nItems;
+        // The next item's loads are issued by quad 0 before its first MFMA phase and by quad 1 after it (same staggering as the
+        // shifted copies below): ~3 k cycles of address arithmetic and VMEM issue per wave that would otherwise idle the matrix pipe.
+        if (more_items && pair == 0) prefetch(it + g.G);
         // ---- materialise the T shifted copies of row rx, pixels [32ks, 32ks+32) into As buffer `buf`:
         //      As[pl][dx][i][k] = Xr[pl][i][rx][8+32ks+k+dx-PAD]
         constexpr int NSTEP = (BRB / 2) * (BKW / 32);
@@ -309,6 +312,7 @@ __device__ __forceinline__ void joint_bf16_body(const float* __restrict__ x, con
                 }
             }
             if (pair == 1 && step + 1 < NSTEP) materialise(step + 1, (step + 1) & 1);
+            if (step == 0 && more_items && pair == 1) prefetch(it + g.G);
             __syncthreads();   // step s+1's copies complete; buffer s & 1 free for step s+2
         }
     }
