@@ -568,11 +568,18 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
     // v_mfma_f32_32x32x16_bf16: one 32 co x 32 ci tile per tap (16 fp32 per lane), k = 16 pixels per step.  Lane map:
     // operand row/col = lane & 31, k-half (8 pixels) = lane >> 5; the 16-lane groups of ds_read_b64_tr_b16 are therefore
     // (channels 0-15 | 16-31) x (pixels 0-7 | 8-15) = (g16 & 1, g16 >> 1).  Half the LDS bytes per flop of 16x16x32.
-    f32x16 acc[9];
+    // Work split over the 4 waves BY TAP: wave w owns taps 2w and 2w+1 for all 8 rows of a tile, and the two rows 2w, 2w+1 of
+    // tap 8.  A tap's accumulator then lives in exactly one wave: taps 0-7 leave through one parallel LDS write, only tap 8
+    // (1/9 of the tile) is summed over the waves.  With rows split over the waves instead, all 9 x 16 accumulator registers of
+    // every wave went through four serial read-modify-write rounds per block -- a quarter of the kernel's time (measured).
+    f32x16 acc[3];
 #pragma unroll
-    for (int b = 0; b < 9; ++b)
+    for (int b = 0; b < 3; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int tap0 = 2 * wvu, tap1 = 2 * wvu + 1;
+    const int off0 = ((tap0 / 3) * IW + tap0 % 3) * 16, off1 = ((tap1 / 3) * IW + tap1 % 3) * 16, off8 = (2 * IW + 2) * 16;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int g16 = lane >> 4, chh = g16 & 1, pxh = g16 >> 1;
 
@@ -624,40 +631,50 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
         }
         __syncthreads();
         if (tile + nsplit < ntiles) fetch(tile + nsplit);
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = wv * 2 + rr;
+#pragma unroll 2
+        for (int row = 0; row < WG_TH; ++row) {
             const short* gb = Gs + (chh * NPX + row * WG_TW + 8 * pxh) * 16;
             const bf16x8_t a0 = tr_frag(gb, q, p4), a1 = tr_frag(gb + 16 * 16, q, p4);     // pixels 0-15 | 16-31 of the row
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
-                const short* ib = Is + (chh * NIPX + (row + ky) * IW + kx + 8 * pxh) * 16;
-                const bf16x8_t b0 = tr_frag(ib, q, p4), b1 = tr_frag(ib + 16 * 16, q, p4);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tap], 0, 0, 0);
+            const short* ib = Is + (chh * NIPX + row * IW + 8 * pxh) * 16;
+            {
+                const bf16x8_t b0 = tr_frag(ib + off0, q, p4), b1 = tr_frag(ib + off0 + 16 * 16, q, p4);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0], 0, 0, 0);
+            }
+            {
+                const bf16x8_t b0 = tr_frag(ib + off1, q, p4), b1 = tr_frag(ib + off1 + 16 * 16, q, p4);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1], 0, 0, 0);
+            }
+            if ((row >> 1) == wvu) {
+                const bf16x8_t b0 = tr_frag(ib + off8, q, p4), b1 = tr_frag(ib + off8 + 16 * 16, q, p4);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[2], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[2], 0, 0, 0);
             }
         }
     }
-    // reduce the 4 waves in LDS (fixed order), write partial [split][co 32][tap 9][ci 32]
-    // D[row = co = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = ci = lane & 31]
-    float* Ds = reinterpret_cast<float*>(wsm_raw);  // 32 x 288 floats = 36.9 KB (fits: G+I tiles are 38.1 KB)
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wv == w) {
+    // partial [split][co 32][tap 9][ci 32] through LDS.  D[row = co = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = ci = lane & 31]
+    float* Ds = reinterpret_cast<float*>(wsm_raw);  // [32][288]; then the four waves' tap-8 planes [4][32][32]
+    float* D8 = Ds + 32 * 288;
+    __syncthreads();                                // the operand tiles are dead
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = tap * 32 + (lane & 31);
-                    if (w == 0) Ds[co * 288 + col] = acc[tap][r];
-                    else Ds[co * 288 + col] += acc[tap][r];
-                }
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = lane & 31;
+        Ds[co * 288 + tap0 * 32 + ci] = acc[0][r];
+        Ds[co * 288 + tap1 * 32 + ci] = acc[1][r];
+        D8[wvu * 1024 + co * 32 + ci] = acc[2][r];
     }
     __syncthreads();
     float* outp = partials + (((size_t)split * gridDim.z + blockIdx.z) * gridDim.y + blockIdx.y) * (32 * 288);
-    for (int e = tid; e < 32 * 288; e += kCT) outp[e] = Ds[e];
+    for (int e = tid; e < 32 * 288; e += kCT) {
+        const int co = e / 288, col = e - co * 288;
+        float v = Ds[e];
+        if (col >= 256) {
+            const int i8 = co * 32 + col - 256;
+            v = (D8[i8] + D8[1024 + i8]) + (D8[2048 + i8] + D8[3072 + i8]);
+        }
+        outp[e] = v;
+    }
 }
 
 // Narrow-layer variant (the 256^2 / 128^2 layers that are HBM-bound): a block owns 16 output channels (grid.z) x one
@@ -1002,7 +1019,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<float>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws);
     } else if (dt == MISEG_BF16) {
         MISEG_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "conv3x3_wgrad: bf16 needs channel counts that are multiples of 8");
-        const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2, (size_t)32 * 288 * 4);
+        const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2, (size_t)(32 * 288 + 4 * 1024) * 4);
         // narrow layers (measured per shape, scratch/time_conv.py): the lean 16x16-tile kernel wins when one side has <= 16
         // channels (256^2 16->16: 125 -> 52 us, 32->16: 129 -> 83, 128^2 16->32: 85 -> 48) and for 32->64 (71 -> 53);
         // from 32->32 up the 32x32-tile kernel's operand reuse wins
