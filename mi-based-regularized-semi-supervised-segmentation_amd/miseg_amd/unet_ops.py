@@ -190,7 +190,8 @@ class _ConvBNReLU(torch.autograd.Function):
             call("miseg_bn_eval_coeffs", _stream(), cout, _ptr(gamma), _ptr(beta), BN_EPS, _ptr(running_mean), _ptr(running_var), _ptr(saved))
         y = empty_nhwc(n, cout, h, w, dtype, dev)
         pooled = empty_nhwc(n, cout, h // 2, w // 2, dtype, dev) if want_pool else None
-        call("miseg_bn_relu_fwd", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(saved), _ptr(y), _ptr(pooled))
+        call("miseg_bn_relu_fwd", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(saved), _ptr(y), _ptr(pooled),
+             work=(0.0, float(es) * n * h * w * cout * (2.25 if want_pool else 2.0)), tag=f"bn_relu_fwd[{h}x{w},{cout}]")
         ctx.save_for_backward(x0, x1, weight, gamma, raw, y, saved)
         ctx.param_refs = (weight, gamma, beta)   # the Parameter objects (flat-gradient slots hang off them)
         ctx.cfg = (training, ups0, ups1, want_pool, c0, c1, n, h, w, cout)
@@ -216,7 +217,8 @@ class _ConvBNReLU(torch.autograd.Function):
             gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
         call("miseg_bn_relu_bwd", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
-             int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel())
+             int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(),
+             work=(0.0, float(raw.element_size()) * n * h * w * cout * 5.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
         gw = None
         if ctx.needs_input_grad[2]:
             gw = grad_slot(pw)
