@@ -87,8 +87,12 @@ __global__ __launch_bounds__(kLT) void softmax_mse_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out) {
     __shared__ float red[17];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    // independent loads first (a dependent load-add chain over 8 partials per thread was ~50 us of pure latency), fixed order
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int i = threadIdx.x + 256 * j; v[j] = i < n ? partials[i] : 0.f; }
+    float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int i = threadIdx.x + 2048; i < n; i += 256) s += partials[i];
     s = block_sum(s, red);
     if (threadIdx.x == 0) out[0] = s * scale;
 }
