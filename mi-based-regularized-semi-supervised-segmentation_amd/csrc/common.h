@@ -111,14 +111,16 @@ static inline unsigned reduce_grid(int64_t total, int64_t nparts) {
     return (unsigned)((total + (nparts >= kWideReduceParts ? 15 : 63)) / (nparts >= kWideReduceParts ? 16 : 64));
 }
 
-template <typename MapFn>
+// `map(e)`: offset of reduction element e inside one part; `omap(e)`: where its sum goes in `out` (negative: nowhere).  Keep
+// consecutive e contiguous in the PARTS (that is where the bytes are); let the output index take the permutation.
+template <typename MapFn, typename OutFn>
 __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
-                                                      float* __restrict__ out, MapFn map) {
+                                                      float* __restrict__ out, MapFn map, OutFn omap) {
     __shared__ float rp_sm[16][64];
     if (nparts <= kFlatReduceParts) {
         // few parts, many outputs: one thread per output, the parts summed in order from registers (no LDS, no barrier)
         const int e = blockIdx.x * 256 + threadIdx.x;
-        if (e < total) {
+        if (e < total && omap(e) >= 0) {
             const float* p = parts + map(e);
             float v[kFlatReduceParts];
 #pragma unroll
@@ -126,7 +128,8 @@ __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ 
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < kFlatReduceParts; ++q) s += v[q];
-            out[e] = s;
+            const int oi = omap(e);
+            if (oi >= 0) out[oi] = s;
         }
         return;
     }
@@ -135,7 +138,7 @@ __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ 
         // then a fixed-order tree over the groups -- same result for any grid, ~16x the loads in flight of the narrow form
         const int o = threadIdx.x & 15, grp = threadIdx.x >> 4, e = blockIdx.x * 16 + o;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (e < total) {
+        if (e < total && omap(e) >= 0) {      // elements without a destination (tile padding) are not read at all
             const float* p = parts + map(e);
             int q = grp;
             for (; q + 48 < nparts; q += 64) {
@@ -152,19 +155,29 @@ __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ 
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) s += rp_sm[g][o];
-            out[e] = s;
+            const int oi = omap(e);
+            if (oi >= 0) out[oi] = s;
         }
         return;
     }
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s = 0.f;
-    if (e < total) {
+    if (e < total && omap(e) >= 0) {
         const size_t off = map(e);
         for (int q = grp; q < nparts; q += 4) s += parts[(size_t)q * stride + off];
     }
     rp_sm[grp][threadIdx.x & 63] = s;
     __syncthreads();
-    if (grp == 0 && e < total) out[e] = ((rp_sm[0][threadIdx.x] + rp_sm[1][threadIdx.x]) + rp_sm[2][threadIdx.x]) + rp_sm[3][threadIdx.x];
+    if (grp == 0 && e < total) {
+        const int oi = omap(e);
+        if (oi >= 0) out[oi] = ((rp_sm[0][threadIdx.x] + rp_sm[1][threadIdx.x]) + rp_sm[2][threadIdx.x]) + rp_sm[3][threadIdx.x];
+    }
+}
+
+template <typename MapFn>
+__device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
+                                                      float* __restrict__ out, MapFn map) {
+    reduce_partials_block(parts, nparts, stride, total, out, map, [](int e) { return e; });
 }
 
 // Flip-aware source coordinate: bit0 = flip H, bit1 = flip W.

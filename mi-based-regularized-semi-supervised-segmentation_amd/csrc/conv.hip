@@ -782,10 +782,13 @@ __global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc 
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nsplit, int Cout, int Cin, int nco,
                                                            int nci, float* __restrict__ gw) {
+    // walk the partial tiles in THEIR order ([co tile][ci tile][co 32][tap 9][ci 32]: consecutive threads read consecutive
+    // floats of every part); the weight-gradient index takes the permutation (read many parts, write once)
     const size_t stride = (size_t)nco * nci * (32 * 288);
-    reduce_partials_block(partials, nsplit, stride, Cout * Cin * 9, gw, [=](int e) {
-        const int tap = e % 9, ci = (e / 9) % Cin, co = e / (9 * Cin);
-        return ((size_t)(co / 32) * nci + ci / 32) * (32 * 288) + (co % 32) * 288 + tap * 32 + (ci % 32);
+    reduce_partials_block(partials, nsplit, stride, nco * nci * 32 * 288, gw, [](int e) { return (size_t)e; }, [=](int e) {
+        const int ci32 = e & 31, tap = (e >> 5) % 9, co32 = (e / 288) & 31, tile = e / (32 * 288);
+        const int co = (tile / nci) * 32 + co32, ci = (tile % nci) * 32 + ci32;
+        return (co < Cout && ci < Cin) ? (co * Cin + ci) * 9 + tap : -1;
     });
 }
 
@@ -1034,7 +1037,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
         }
     } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
     MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
-    const int total = (int)(Cout * Cin * 9);
+    const int total = nco * nci * 32 * 288;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(total, ns)), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
     MISEG_LAUNCH_CHECK("wgrad_reduce_kernel");
     return MISEG_OK;
