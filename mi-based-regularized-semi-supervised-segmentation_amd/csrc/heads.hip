@@ -7,6 +7,10 @@
 
 namespace miseg {
 
+typedef __bf16 bf16x8h_t __attribute__((ext_vector_type(8)));
+#define HLDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
+
+
 constexpr int kHT = 256;
 
 template <typename T> struct Vec4;
@@ -294,8 +298,12 @@ __global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restri
 //   phase 2 (fp32 MFMA):       gfeat[px][c] = sum_(s,k) dz[(s,k)][px] * W[(s,k)][c]     (M=px, N=c, Kred=S*K)
 //   phase 3 (fp32 MFMA):       gw[(s,k)][c] += sum_px dz[(s,k)][px] * f[px][c]          (M=(s,k), N=c, Kred=px)
 // gw / gb accumulate in registers across the block's chunks; one deterministic partial per block at the end.
-template <typename T, int CTM, int RW, bool K20>   // K20: K == 20 and S*K <= 100 -> a row's sub-head is i / 5, a compile-time index
-__global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
+// BF (bf16 features, K20 only): phases 2 and 3 run on v_mfma_f32_16x16x32_bf16 instead of the fp32 16x16x4 form (5x the MACs per
+// matrix-pipe cycle).  dz is kept in LDS as two bf16 planes (hi + lo, 2^-16 relative), the weights as two transposed bf16 planes,
+// the features are bf16 already (exact): gw = (dz_hi + dz_lo) . f, gfeat = W_hi.dz_hi + W_hi.dz_lo + W_lo.dz_hi (then rounded
+// to bf16 anyway).  The fp32 build keeps the exact fp32 MFMA path.
+template <typename T, int CTM, int RW, bool K20, bool BF>   // K20: K == 20 and S*K <= 100 -> a row's sub-head is i / 5, a compile-time index
+__global__ __launch_bounds__(256, (CTM == 1 && !BF ? 3 : 2)) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                    int M, const float* __restrict__ w, int S, int K, float invT,
                                                                    const float* __restrict__ prob, const float* __restrict__ gprob,
@@ -305,16 +313,33 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
     constexpr int DZS = 65;
     constexpr int FPT = CTM * 4;              // feature values per thread: 64 px * (CTM*16) channels / 256 threads
     const int FS = C + 1, WS = C + 1;
+    constexpr int RPB = 128, DZB = 72, WTB = 136, CP = CTM * 16;   // BF layout: rows padded to 4 k-steps of 32; strides conflict-free for b128
     float* dzs = sm;                          // [RP][DZS]   p*g, then dz; rows >= R zero
     float* fs = dzs + (size_t)RP * DZS;       // [64][FS]    feature chunk (fp32)
     float* wsm = fs + (size_t)64 * FS;        // [RP][WS]    head weights, rows >= R zero
     float* dots = wsm + (size_t)RP * WS;      // [4 waves][S][64]  partial <g,p> per (wave, sub-head, pixel); generic path: [S][64]
+    unsigned short* dzb = reinterpret_cast<unsigned short*>(sm);      // BF: [2][RPB][DZB]  dz hi | lo (bf16 bits), rows >= R zero
+    unsigned short* fsT = dzb + 2 * RPB * DZB;                         // BF: [CP][DZB]      features transposed [c][px]
+    unsigned short* wT = fsT + CP * DZB;                               // BF: [2][CP][WTB]   W^T hi | lo: [c][r], r >= R zero
+    if (BF) dots = reinterpret_cast<float*>(wT + 2 * CP * WTB);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    for (int idx = tid; idx < RP * C; idx += 256) {
-        const int c = idx % C, r = idx / C;
-        wsm[r * WS + c] = r < R ? w[(size_t)r * C + c] : 0.f;
+    if (BF) {
+        for (int idx = tid; idx < 2 * RPB * DZB; idx += 256) dzb[idx] = 0;
+        for (int idx = tid; idx < CP * DZB; idx += 256) fsT[idx] = 0;
+        for (int idx = tid; idx < CP * WTB; idx += 256) {
+            const int c = idx / WTB, r = idx - c * WTB;
+            const float v = (r < R && c < C) ? w[(size_t)r * C + c] : 0.f;
+            const unsigned short hi = f32_to_bf16_bits(v);
+            wT[idx] = hi;
+            wT[CP * WTB + idx] = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+        }
+    } else {
+        for (int idx = tid; idx < RP * C; idx += 256) {
+            const int c = idx % C, r = idx / C;
+            wsm[r * WS + c] = r < R ? w[(size_t)r * C + c] : 0.f;
+        }
+        for (int idx = tid; idx < (RP - R) * 64; idx += 256) dzs[(R + idx / 64) * DZS + (idx & 63)] = 0.f;
     }
-    for (int idx = tid; idx < (RP - R) * 64; idx += 256) dzs[(R + idx / 64) * DZS + (idx & 63)] = 0.f;
     f32x4 accw[4][CTM];   // gw: row tiles rt = wv + 4a, column tiles c
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -391,7 +416,10 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
         }
 #pragma unroll
         for (int j = 0; j < FPT; ++j)
-            if (tid + 256 * j < 64 * C) fs[fq[j] * FS + fc[j]] = (p0 + fq[j] < HW) ? to_f32(fr[j]) : 0.f;
+            if (tid + 256 * j < 64 * C) {
+                if (BF) fsT[fc[j] * DZB + fq[j]] = (p0 + fq[j] < HW) ? *reinterpret_cast<const unsigned short*>(&fr[j]) : (unsigned short)0;
+                else fs[fq[j] * FS + fc[j]] = (p0 + fq[j] < HW) ? to_f32(fr[j]) : 0.f;
+            }
         __syncthreads();
         if (K20) {
             float dot[5];
@@ -403,7 +431,13 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
                 const int r = wvu + 4 * i;
                 const float dz = pr[i] * (gr[i] - dot[i / 5]) * invT;
                 if (r < R) {
-                    dzs[r * DZS + px] = dz;
+                    if (BF) {
+                        const unsigned short hi = f32_to_bf16_bits(dz);
+                        dzb[r * DZB + px] = hi;
+                        dzb[(RPB + r) * DZB + px] = f32_to_bf16_bits(dz - bf16_bits_to_f32(hi));
+                    } else {
+                        dzs[r * DZS + px] = dz;
+                    }
                     gbr[i] += dz;
                 }
             }
@@ -439,15 +473,42 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
             f32x4 accf[CTM];
 #pragma unroll
             for (int c = 0; c < CTM; ++c) accf[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 7
-            for (int ks = 0; ks < RP; ks += 4) {
-                const float av = dzs[(ks + kq) * DZS + wv * 16 + l15];
+            if (BF) {
+                // D[c][px] = sum_r W^T[c][r] dz[r][px]: A = W^T rows (b128), B = dz columns through the transposing LDS read
+                // (lane 4*qq+pq of a 16-lane group reads 4 pixels of row k0+qq and receives its own pixel's 4 rows)
+                const int qq = l15 >> 2, pq = l15 & 3;
 #pragma unroll
-                for (int c = 0; c < CTM; ++c)
-                    if (c < CT) {
-                        const float bv = wsm[(ks + kq) * WS + min(c * 16 + l15, C - 1)];
-                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, accf[c], 0, 0, 0);
+                for (int ks = 0; ks < RPB / 32; ++ks) {
+                    bf16x8h_t bz[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const unsigned short* b0 = dzb + (size_t)(pl * RPB + ks * 32 + 8 * kq + qq) * DZB + wv * 16 + 4 * pq;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(HLDS_S16X4(b0));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(HLDS_S16X4(b0 + 4 * DZB));
+                        const s16x8 fv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        bz[pl] = __builtin_bit_cast(bf16x8h_t, fv);
                     }
+#pragma unroll
+                    for (int c = 0; c < CTM; ++c) {
+                        const unsigned short* a0 = wT + (size_t)(c * 16 + l15) * WTB + ks * 32 + 8 * kq;
+                        const bf16x8h_t whi = *reinterpret_cast<const bf16x8h_t*>(a0);
+                        const bf16x8h_t wlo = *reinterpret_cast<const bf16x8h_t*>(a0 + CP * WTB);
+                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, bz[0], accf[c], 0, 0, 0);
+                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, bz[1], accf[c], 0, 0, 0);
+                        accf[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, bz[0], accf[c], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll 7
+                for (int ks = 0; ks < RP; ks += 4) {
+                    const float av = dzs[(ks + kq) * DZS + wv * 16 + l15];
+#pragma unroll
+                    for (int c = 0; c < CTM; ++c)
+                        if (c < CT) {
+                            const float bv = wsm[(ks + kq) * WS + min(c * 16 + l15, C - 1)];
+                            accf[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, accf[c], 0, 0, 0);
+                        }
+                }
             }
             // D^T[row = channel c*16 + kq*4 + r][col = pixel l15]
             const int pq = p0 + wv * 16 + l15;
@@ -472,6 +533,29 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
             }
         }
         // ---- phase 3: gw += dz * f
+        if (BF) {
+            // D[r][c] = sum_px dz[r][px] f[px][c]: A = dz rows (hi, lo planes), B = transposed features, both plain b128 reads
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8h_t bf_[CTM];
+#pragma unroll
+                for (int c = 0; c < CTM; ++c) bf_[c] = *reinterpret_cast<const bf16x8h_t*>(fsT + (size_t)(c * 16 + l15) * DZB + ks * 32 + 8 * kq);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int rt = wv + 4 * a;           // 7 row tiles over 4 waves
+                    if (rt < RT) {
+                        const unsigned short* a0 = dzb + (size_t)(rt * 16 + l15) * DZB + ks * 32 + 8 * kq;
+                        const bf16x8h_t dhi = *reinterpret_cast<const bf16x8h_t*>(a0);
+                        const bf16x8h_t dlo = *reinterpret_cast<const bf16x8h_t*>(a0 + (size_t)RPB * DZB);
+#pragma unroll
+                        for (int c = 0; c < CTM; ++c) {
+                            accw[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dlo, bf_[c], accw[a][c], 0, 0, 0);
+                            accw[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dhi, bf_[c], accw[a][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < 64; ks += 4) {
             float bfr[CTM];
@@ -575,15 +659,19 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     hipStream_t st = as_stream(stream);
     float* partials = (float*)ws;
     const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16, RP = RT * 16;
-    const size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1) + (size_t)4 * std::max<int64_t>(S, 5) * 64) * 4;
+    size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1) + (size_t)4 * std::max<int64_t>(S, 5) * 64) * 4;
+    {   // the bf16-MFMA variant's layout: dz planes [2][128][72], features^T [CP][72], W^T planes [2][CP][136] (bf16) + dots
+        const size_t cp = (size_t)((C + 15) / 16) * 16;
+        lds = std::max(lds, ((size_t)2 * 128 * 72 + cp * 72 + 2 * cp * 136) * 2 + (size_t)4 * 5 * 64 * 4);
+    }
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
-#define HLB2(TT, CTM, RW, K20V)                                                                                                         \
+#define HLB2(TT, CTM, RW, K20V, BFV)                                                                                                         \
     {                                                                                                                             \
-        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW, K20V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW, K20V>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
+        hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW, K20V, BFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW, K20V, BFV>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
                            src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);            \
     }
-#define HLB(TT, CTM) { if (K == 20 && R <= 100) HLB2(TT, CTM, 28, true) else if (R <= 112) HLB2(TT, CTM, 28, false) else HLB2(TT, CTM, 64, false) }
+#define HLB(TT, CTM) { if (K == 20 && R <= 100 && sizeof(TT) == 2 && CTM == 2 && C == 32) HLB2(TT, CTM, 28, true, true)   /* 16 channels: HBM-bound either way, keeps 3 blocks per CU */ else if (K == 20 && R <= 100) HLB2(TT, CTM, 28, true, false) else if (R <= 112) HLB2(TT, CTM, 28, false, false) else HLB2(TT, CTM, 64, false, false) }
 #define HLB_C(TT) { if (C <= 16) HLB(TT, 1) else if (C <= 32) HLB(TT, 2) else if (C <= 64) HLB(TT, 4) else HLB(TT, 8) }
     if (dt == MISEG_F32) HLB_C(float)
     else if (dt == MISEG_BF16) HLB_C(bf16)

@@ -321,3 +321,30 @@ def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch):
     np.testing.assert_allclose(fused.detach().cpu().numpy(), loop.detach().cpu().numpy(), rtol=0, atol=5e-7)
     gscale = float(b.grad.abs().max())
     np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=0, atol=2e-4 * gscale)
+
+
+@pytest.mark.parametrize("c,h", [(32, 40), (16, 24)])
+def test_local_head_backward_shipped_shape_bf16_vs_fp32_kernels(c, h):
+    """S=5 x K=20 heads on bf16 features (the shipped taps).  C=32 takes the bf16-MFMA backward (dz as hi+lo bf16 planes, W^T
+    hi+lo, exact bf16 features), C=16 the K=20 register path; both against the exact-fp32 kernels on the same (bf16-valued)
+    features.  gw / gb: 2e-4 of the gradient scale (hi+lo = 2^-16 per term); gfeat is a bf16 tensor: one bf16 ulp."""
+    torch.manual_seed(3)
+    b_, m = 6, 4
+    feat16 = torch.randn(b_, c, h, h + 8, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(5, 20, c, device=DEV) * 0.3).requires_grad_(True)
+    b = torch.randn(5, 20, device=DEV).requires_grad_(True)
+    src = torch.tensor([1, 3, 4, 5], dtype=torch.int32, device=DEV)
+    flips = torch.tensor([0, 1, 2, 3], dtype=torch.int32, device=DEV)
+    outs = []
+    for ft in (feat16, feat16.float().contiguous(memory_format=torch.channels_last)):
+        f = ft.clone().requires_grad_(True)
+        prob = ops().local_head(f, w, b, src, flips, 1.0)
+        cot = torch.randn(prob.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+        gf, gw, gb = torch.autograd.grad((prob * cot).sum(), [f, w, b])
+        outs.append((prob.detach(), gf.float(), gw, gb))
+    (p16, gf16, gw16, gb16), (p32, gf32, gw32, gb32) = outs
+    assert torch.allclose(p16, p32, rtol=1e-5, atol=1e-7)
+    for a16, a32 in ((gw16, gw32), (gb16, gb32)):
+        assert float((a16 - a32).abs().max()) <= 2e-4 * float(a32.abs().max())
+    assert float((gf16 - gf32).abs().max()) <= 2.0 ** -7 * float(gf32.abs().max())
+    assert float(gf32[0].abs().max()) == 0.0 and float(gf16[0].abs().max()) == 0.0      # untouched source rows stay zero
