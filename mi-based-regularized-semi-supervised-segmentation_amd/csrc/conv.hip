@@ -847,8 +847,15 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
         float f[CI], g[CO];
 #pragma unroll
         for (int c = 0; c < CI; ++c) f[c] = to_f32(fe[c]);
+        if (CO == 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gout + i * 4);
+            g[0] = g4.x; g[1 % CO] = g4.y; g[2 % CO] = g4.z; g[3 % CO] = g4.w;
+        } else {
 #pragma unroll
-        for (int o = 0; o < CO; ++o) { g[o] = gout[i * CO + o]; gbacc[o] += g[o]; }
+            for (int o = 0; o < CO; ++o) g[o] = gout[i * CO + o];
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) gbacc[o] += g[o];
         uint4 vout[NV];
         T* oe = reinterpret_cast<T*>(vout);
 #pragma unroll
@@ -1063,7 +1070,8 @@ extern "C" int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N
     return MISEG_OK;
 }
 
-static int c1_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv(npix, 256), 1024); }
+// 2 blocks per CU: the per-block epilogue (68 wave reductions) costs as much as ~20 pixels of the main loop
+static int c1_blocks(int64_t npix) { return (int)std::min<int64_t>(cdiv(npix, 256), 512); }
 extern "C" int64_t miseg_conv1x1_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
     return ((int64_t)c1_blocks(N * H * W) + 1) * (Cout * Cin + Cout) * 4;
 }
