@@ -499,6 +499,9 @@ def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True
 
 
 # ------------------------------------------------------------------------------------------ split with a layout-preserving backward
+_SPLIT_MEMCPY = __import__("os").environ.get("MISEG_SPLIT_MEMCPY", "0") == "1"   # A/B switch
+
+
 class _SplitRows(torch.autograd.Function):
     """``torch.split(x, sizes, dim=0)`` whose backward assembles the gradient directly in x's memory format.
 
@@ -528,7 +531,10 @@ class _SplitRows(torch.autograd.Function):
             if g is None:
                 part.zero_()
             else:
-                part.copy_(g)
+                if _SPLIT_MEMCPY:
+                    part.copy_(g)
+                else:
+                    torch.mul(g, 1.0, out=part)   # an elementwise kernel: copy_ of two dense tensors is a hipMemcpyDtoD, seen at 1.5 ms for 16 MB
             o += n
         return (out,) + (None,) * len(ctx.sizes)
 
