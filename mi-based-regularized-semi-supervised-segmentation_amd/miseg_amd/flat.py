@@ -119,7 +119,10 @@ class FlatBuffers:
                 if g is None:
                     slot.zero_()
                 elif g.data_ptr() != slot.data_ptr():
-                    slot.copy_(g)
+                    if slot.is_cuda and g.dtype == slot.dtype and g.shape == slot.shape:
+                        torch.mul(g, 1.0, out=slot)    # a kernel, not hipMemcpyDtoD (which can stall for 100s of us on a busy device)
+                    else:
+                        slot.copy_(g)
                 else:
                     continue
                 p.grad = slot
