@@ -1,7 +1,9 @@
 """GPU parity of the WHOLE train step through the reference-compatible surface: my UDAIICEpocher / TrainEpocher
 (HIP kernels, exact-fp32 mode) vs the meters, gradients and updated weights the reference's own epochers produced
 on the same synthetic state and batches (tests/golden/step.npz)."""
+import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -176,3 +178,26 @@ print("GRAPH_EQUALS_EAGER")
 """ % (root, os.path.join(root, "mi-based-regularized-semi-supervised-segmentation_amd"))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "GRAPH_EQUALS_EAGER" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the driver's fields, the roofline object of the dominant kernel and the CPU
+    baseline object (small shape here; the default invocation is the BASELINE configuration)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--lb", "2", "--ub", "2", "--size", "64"],
+                         cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    rl = d["roofline"]
+    assert rl["bound"] in ("hbm", "mfma") and rl["achieved"] > 0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "workload" in d["config"]
