@@ -14,6 +14,9 @@
 //   * B: the source tile stays planar [c][row][w] in LDS; ds_read_b64_tr_b16 transposes 4 planes x 16 pixels on the fly into
 //     the 8-consecutive-k lane layout.  Rows live in a 12-row ring (3 groups of 4): a block walks a segment of consecutive
 //     4-row items down one 58-column strip and fetches only the 4 new rows per item (registers, one item ahead);
+//     The first two k-steps of A (37 KB) are kept in LDS for a whole segment -- every item of a segment multiplies by the same
+//     G -- and only the other k-steps are loaded per wave from L2; the half-1 waves park their partial sums in their own col2im
+//     staging tile (read by the row's half-0 wave between the next item's two barriers), which is what frees that LDS;
 //   * col2im is a gather: a wave parks one M-tile of D at a time in LDS as [col][16 rows] and every lane (= one output
 //     column) reads 4 rows per ds_read_b128 at its shifted column; the two M halves are summed through LDS.
 // K and PAD are template parameters (K=20; PAD=3 and 1: the shipped taps); other shapes use the fp32 kernels.
@@ -95,8 +98,10 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r4 = wvu & 3, half = wvu >> 2;
     float* Dw = Dst + (size_t)wvu * WT * DL;
-    float* Park = Dst + (size_t)8 * WT * DL;                                     // [2 item parities][4 rows][64 cols][DL]: half 1 -> half 0
-    int itc = 0;                                                                 // items done by this block
+    // the first CK k-steps of A stay in LDS for a whole segment (same G for all its items): filled once per segment, read by
+    // every wave at LDS bandwidth; only the remaining k-steps travel L2 -> registers per wave
+    constexpr int CK = KS < 2 ? KS : 2;
+    unsigned short* Acache = reinterpret_cast<unsigned short*>(Dst + (size_t)8 * WT * DL);   // [CK][SLICE]
     const size_t plane = (size_t)g.H * g.W;
 
     // ---- segments: (dir, window p, sample n, column strip ct, run of <= L consecutive 4-row items)
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
     // Branch-free: a lane without an output (tile halo, past the window, nothing pending yet) stores to an out-of-range buffer
     // offset, which the hardware drops.
     auto finish_output = [&]() {
-        const float* Dpartner = Park + (size_t)((((itc - 1) & 1) * 4 + r4) * WT) * DL;   // parked by the row's half-1 wave last item
+        const float* Dpartner = Dst + (size_t)(wvu + 4) * WT * DL;   // the row's half-1 wave parked its partial sums in its own staging tile
 #pragma unroll
         for (int o4 = 0; o4 < K; o4 += 4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(Dpartner + lane * DL + o4);
@@ -193,26 +198,21 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
 
     const int64_t nseg = 2 * total;
     Seg sg, sgn_;
-    // A fragments: "step" = (k-step, M tile) in execution order; a wave keeps the fragments of AHEAD steps in flight in a ring
-    // of AHEAD + 1 register slots, across item boundaries (a0 = the first AHEAD steps of the upcoming item).
-    constexpr int AHEAD = 2;
-    u32x4 a0[AHEAD][NP];
+    // A fragments of the uncached k-steps: "step" = (k-step - CK, M tile) in execution order; AHEAD steps in flight in a ring of
+    // AHEAD + 1 register slots, issued from the start of the item (the cached k-steps run first and cover the latency).
+    constexpr int AHEAD = 3;
     const int aoff0 = ((l15 * 32) + 8 * (q ^ ((0 - (l15 >> 2)) & 3))) * 2;      // byte offset of this lane's 16 B inside an M tile
     auto rsrc_of = [&](const unsigned short* slices) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)slices, 0, KS * SLICE * 2, 0x00020000);
     };
     auto load_step = [&](__amdgpu_buffer_rsrc_t rs, int mt0, int mtn, int step, u32x4* dst) {
-        const int ks = step / mtn, ml = step - ks * mtn;
+        const int ks = CK + step / mtn, ml = step - (step / mtn) * mtn;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
             dst[pl] = (kAbl & 16) ? u32x4{0u, 0u, 0u, 0u}
                                       : __builtin_amdgcn_raw_buffer_load_b128(rs, aoff0, (ks * SLICE + (pl * MP + (mt0 + ml) * 16) * 32) * 2, 0);
     };
-    if ((int64_t)blockIdx.x < nseg) {
-        decode(blockIdx.x, sg);
-#pragma unroll
-        for (int i = 0; i < AHEAD; ++i) load_step(rsrc_of(slices_of(sg)), half ? MH : 0, half ? MT - MH : MH, i, a0[i]);
-    }
+    if ((int64_t)blockIdx.x < nseg) decode(blockIdx.x, sg);
 #pragma unroll 1
     for (int64_t sid = blockIdx.x; sid < nseg; sid += g.G) {
         const bool more_seg = sid + g.G < nseg;
@@ -227,6 +227,8 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
 #pragma unroll
             for (int u = 0; u < 3; ++u) commit_group((sg.rt0 + u) % 3, w3[u]);
         }
+        for (int idx = tid; idx < CK * SLICE / 8; idx += 512)     // this segment's first CK slices (published by the item's second barrier)
+            *reinterpret_cast<u32x4*>(Acache + (size_t)idx * 8) = *reinterpret_cast<const u32x4*>(gbase + (size_t)idx * 8);
         int base3 = sg.rt0 % 3;                  // ring slot of group rt-1
         float pf[PFN];
 #pragma unroll 1
@@ -255,16 +257,12 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                 for (int ml = 0; ml < MTN; ++ml)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[ml][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const unsigned short* nxt_slices = more_rt ? gbase : more_seg ? slices_of(sgn_) : nullptr;
                 const __amdgpu_buffer_rsrc_t rsA = rsrc_of(gbase);
-                const __amdgpu_buffer_rsrc_t rsN = rsrc_of(nxt_slices != nullptr ? nxt_slices : gbase);
-                constexpr int NS = KS * MTN;
-                static_assert(NS > AHEAD, "ring assumes more steps per item than it prefetches");
+                constexpr int NS = (KS - CK) * MTN;       // uncached steps
                 u32x4 ring[AHEAD + 1][NP];
 #pragma unroll
                 for (int i = 0; i < AHEAD; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) ring[i][pl] = a0[i][pl];
+                    if (i < NS) load_step(rsA, MT0, MTN, i, ring[i]);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (ks == KS - 1) late_work();
@@ -295,14 +293,20 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                     if (!(kAbl & 2))
 #pragma unroll
                         for (int ml = 0; ml < MTN; ++ml) {
-                            constexpr int dummy2 = 0; (void)dummy2;
-                            const int step = ks * MTN + ml;                    // compile-time after unrolling
-                            if (step + AHEAD < NS) load_step(rsA, MT0, MTN, step + AHEAD, ring[(step + AHEAD) % (AHEAD + 1)]);
-                            else load_step(rsN, MT0, MTN, step + AHEAD - NS, ring[(step + AHEAD) % (AHEAD + 1)]);   // no next item: re-reads this one
-                            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch where it is: the scheduler would sink it next to its use
                             bf16x8_t af[NP];
+                            if (ks < CK) {                                     // compile-time after unrolling
+                                __builtin_amdgcn_sched_barrier(0);             // one tile's fragments at a time
+                                const int m = (MT0 + ml) * 16 + l15;
 #pragma unroll
-                            for (int pl = 0; pl < NP; ++pl) af[pl] = __builtin_bit_cast(bf16x8_t, ring[step % (AHEAD + 1)][pl]);
+                                for (int pl = 0; pl < NP; ++pl)
+                                    af[pl] = *reinterpret_cast<const bf16x8_t*>(Acache + (size_t)ks * SLICE + ((size_t)pl * MP + m) * 32 + 8 * (q ^ ((0 - (m >> 2)) & 3)));
+                            } else {
+                                const int step = (ks - CK) * MTN + ml;
+                                if (step + AHEAD < NS) load_step(rsA, MT0, MTN, step + AHEAD, ring[(step + AHEAD) % (AHEAD + 1)]);
+                                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch where it is: the scheduler would sink it next to its use
+#pragma unroll
+                                for (int pl = 0; pl < NP; ++pl) af[pl] = __builtin_bit_cast(bf16x8_t, ring[step % (AHEAD + 1)][pl]);
+                            }
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
                                 if (NTERMS == 3) {
@@ -313,10 +317,6 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                             }
                         }
                 }
-#pragma unroll
-                for (int i = 0; i < AHEAD; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) a0[i][pl] = ring[(NS + i) % (AHEAD + 1)][pl];
                 // ---- col2im gather: lane = output tile column wc; out[o] += D[(b,o)][wc + sgn*(b-PAD)]
 #pragma unroll
                 for (int o = 0; o < K; ++o) outp[o] = 0.f;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
                     }
                 }
                 if (HALF == 1) {                 // park the partial sums for the row's half-0 wave
-                    float* pk = Park + (size_t)(((itc & 1) * 4 + r4) * WT) * DL;
+                    float* pk = Dw;              // read by the half-0 wave between the next item's two barriers, before this tile is staged into again
 #pragma unroll
                     for (int o4 = 0; o4 < K; o4 += 4)
                         *reinterpret_cast<f32x4*>(pk + lane * DL + o4) = f32x4{outp[o4], outp[o4 + 1], outp[o4 + 2], outp[o4 + 3]};
@@ -361,7 +361,6 @@ __global__ __launch_bounds__(512, 1) void local_bwd_bf16_kernel(const float* __r
             else body(std::integral_constant<int, 1>{});
             prow = sg.h0 + 4 * rt + r4; pcol0 = sg.col0; pn = sg.n; pdir = dir; ph1 = sg.h1; pw1 = sg.w1; pp = sg.p; ps = sg.s;
             pending = true;
-            ++itc;
             base3 = base3 == 2 ? 0 : base3 + 1;
         }
         sg = sgn_;
@@ -374,7 +373,8 @@ template <int K, int PAD>
 static size_t bwd3_lds(int nterms) {
     typedef B3<K, PAD> C;
     const int np = nterms == 1 ? 1 : 2;
-    return (size_t)np * K * C::RING * C::SW * 2 + (size_t)(8 + 2 * 4) * C::WT * C::DL * 4;
+    const int ck = C::KS < 2 ? C::KS : 2;
+    return (size_t)np * K * C::RING * C::SW * 2 + (size_t)8 * C::WT * C::DL * 4 + (size_t)ck * np * C::MP * 32 * 2;
 }
 
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad) {
