@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restri
 // the features are bf16 already (exact): gw = (dz_hi + dz_lo) . f, gfeat = W_hi.dz_hi + W_hi.dz_lo + W_lo.dz_hi (then rounded
 // to bf16 anyway).  The fp32 build keeps the exact fp32 MFMA path.
 template <typename T, int CTM, int RW, bool K20, bool BF>   // K20: K == 20 and S*K <= 100 -> a row's sub-head is i / 5, a compile-time index
-__global__ __launch_bounds__(256, (CTM == 1 && !BF ? 3 : 2)) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
+__global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_kernel(const T* __restrict__ feat, int H, int W, int C,
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                    int M, const float* __restrict__ w, int S, int K, float invT,
                                                                    const float* __restrict__ prob, const float* __restrict__ gprob,
@@ -340,9 +340,10 @@ __global__ __launch_bounds__(256, (CTM == 1 && !BF ? 3 : 2)) void head_local_bwd
         }
         for (int idx = tid; idx < (RP - R) * 64; idx += 256) dzs[(R + idx / 64) * DZS + (idx & 63)] = 0.f;
     }
-    f32x4 accw[4][CTM];   // gw: row tiles rt = wv + 4a, column tiles c
+    constexpr int NA = K20 ? 2 : 4;   // row tiles per wave: 7 tiles (R <= 112) over 4 waves with K20, up to 16 otherwise
+    f32x4 accw[NA][CTM];   // gw: row tiles rt = wv + 4a, column tiles c
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int c = 0; c < CTM; ++c) accw[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float gbacc = 0.f;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256, (CTM == 1 && !BF ? 3 : 2)) void head_local_bwd
 #pragma unroll
             for (int c = 0; c < CTM; ++c) bfr[c] = (c < CT) ? fs[(ks + kq) * FS + min(c * 16 + l15, C - 1)] : 0.f;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < NA; ++a) {
                 const int rt = wv + 4 * a;
                 if (rt < RT) {
                     const float av = dzs[(rt * 16 + l15) * DZS + ks + kq];
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256, (CTM == 1 && !BF ? 3 : 2)) void head_local_bwd
     }
     float* out = partials + (size_t)blockIdx.x * (R * C + R);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
         const int rt = wv + 4 * a;
         if (rt < RT) {
 #pragma unroll
@@ -671,7 +672,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
         hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW, K20V, BFV>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
                            src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);            \
     }
-#define HLB(TT, CTM) { if (K == 20 && R <= 100 && sizeof(TT) == 2 && CTM == 2 && C == 32) HLB2(TT, CTM, 28, true, true)   /* 16 channels: HBM-bound either way, keeps 3 blocks per CU */ else if (K == 20 && R <= 100) HLB2(TT, CTM, 28, true, false) else if (R <= 112) HLB2(TT, CTM, 28, false, false) else HLB2(TT, CTM, 64, false, false) }
+#define HLB(TT, CTM) { if (K == 20 && R <= 100 && sizeof(TT) == 2 && CTM == 2 && C == 32) HLB2(TT, CTM, 25, true, true)   /* 16 channels: HBM-bound either way and the bf16 variant does not fit 3 blocks per CU */ else if (K == 20 && R <= 100) HLB2(TT, CTM, 25, true, false) else if (R <= 112) HLB2(TT, CTM, 28, false, false) else HLB2(TT, CTM, 64, false, false) }
 #define HLB_C(TT) { if (C <= 16) HLB(TT, 1) else if (C <= 32) HLB(TT, 2) else if (C <= 64) HLB(TT, 4) else HLB(TT, 8) }
     if (dt == MISEG_F32) HLB_C(float)
     else if (dt == MISEG_BF16) HLB_C(bf16)
