@@ -59,6 +59,9 @@ def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
                "LabeledData": {"shuffle": True, "batch_size": lb}, "UnlabeledData": {"shuffle": True, "batch_size": ub}}
         with contextlib.redirect_stdout(io.StringIO()):
             lab, unl, _ = DH.get_dataloaders(cfg, root_dir=root, seed=rank)
+    elif data == "host":   # pinned host batches: every step pays the H2D copy (the PCIe-inclusive rate of DESIGN.md section 7; never `value`)
+        lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=None)
+        unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=None)
     else:
         lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=device)
         unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=device)
@@ -213,7 +216,7 @@ def main():
                     help="replay the device half of the step as one captured hipGraph (miseg_amd.graph); at the cfg2 shape the step is "
                          "GPU-bound either way (13.6 ms replayed vs 13.5 ms eager), so eager -- with per-kernel events inside the "
                          "timed region -- stays the default")
-    ap.add_argument("--data", default="synthetic", choices=["synthetic", "acdc"],
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "acdc", "host"],
                     help="synthetic = resident ACDC-shaped tensors (BASELINE metric, default); acdc = batches drawn every step by the "
                          "device input pipeline from an ACDC-format PNG set (224^2 crops, as the reference trains)")
     ap.add_argument("--workload", default="step", choices=["step", "input"],
@@ -303,7 +306,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
-            "data": "synthetic" if args.data == "synthetic" else "synthetic ACDC-format PNG set through the device input pipeline (224^2 crops)",
+            "data": {"synthetic": "synthetic", "host": "synthetic, pinned host batches copied to the device every step (PCIe-inclusive)",
+                     "acdc": "synthetic ACDC-format PNG set through the device input pipeline (224^2 crops)"}[args.data],
             "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
                                    f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
                        "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
