@@ -154,6 +154,140 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_reg_kernel(const T* __rest
     if (viol && live && nbad) atomicAdd(viol, nbad);
 }
 
+// MFMA form of the kernel above for the shipped taps (bf16 features, K = 20, C = 16 or 32).  The register kernel spends
+// K*C FMAs per pixel and sub-head on the VALU and is bound by them, not by its 4 bytes-per-probability of output.  Here a wave
+// computes logits[class][pixel] = W x feat^T on the matrix pipe: the fp32 weights are split once per block into three bf16
+// planes (w = h1 + h2 + h3 to within 2^-25 relative, the features are bf16 already, the products exact and the accumulation
+// fp32), so the logits agree with the FMA chain to rounding order.  The D tiles (4 classes x 1 pixel per lane) go through a
+// per-wave LDS transpose, 128 pixels at a time, into the softmax layout of the register kernel (4 consecutive pixels x 20
+// classes per lane), and the epilogue -- exp2 softmax, simplex check, one 16-byte store per class plane -- is that kernel's.
+typedef __bf16 bf16x4h_t __attribute__((ext_vector_type(4)));
+template <int C> struct HeadFrag;
+template <> struct HeadFrag<32> {
+    typedef bf16x8h_t type;
+    static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct HeadFrag<16> {
+    typedef bf16x4h_t type;
+    static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
+};
+constexpr int kHeadZS = 132;   // floats per class row of a wave's transpose buffer (128 pixels + 4: conflict-free D writes)
+template <int C> constexpr int head_mfma_cp() { return C + 8; }
+template <int C>
+__global__ __launch_bounds__(kHT) void head_local_fwd_mfma_kernel(const bf16* __restrict__ feat, int H, int W,
+                                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
+                                                                  int M, const float* __restrict__ w, const float* __restrict__ b, int S,
+                                                                  float invT, float* __restrict__ prob, float tol,
+                                                                  int32_t* __restrict__ viol) {
+    constexpr int K = 20, ZS = kHeadZS, CP = head_mfma_cp<C>(), CQ = C / 4;
+    typedef typename HeadFrag<C>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hl[];
+    float* ztw = reinterpret_cast<float*>(hl) + (size_t)(threadIdx.x >> 6) * K * ZS;   // this wave's [K][ZS]
+    bf16* wp = reinterpret_cast<bf16*>(hl + (size_t)(kHT / 64) * K * ZS * 4);            // [S][3][K][CP]
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int HW = H * W, m = blockIdx.y;
+    for (int i = tid; i < S * K * C; i += kHT) {
+        const float v = w[i];
+        const bf16 h1 = __float2bfloat16(v);
+        const float r1 = v - __bfloat162float(h1);
+        const bf16 h2 = __float2bfloat16(r1);
+        const bf16 h3 = __float2bfloat16(r1 - __bfloat162float(h2));
+        const int s = i / (K * C), rem = i - s * K * C, k = rem / C, c = rem - k * C;
+        bf16* d = wp + ((size_t)(s * 3) * K + k) * CP + c;
+        d[0] = h1, d[(size_t)K * CP] = h2, d[(size_t)2 * K * CP] = h3;
+    }
+    __syncthreads();
+    const int f = flips ? flips[m] : 0;
+    const int wbase = (blockIdx.x * (kHT / 64) + (tid >> 6)) * 256;   // first pixel of this wave
+    const bf16* fs = feat + (size_t)src[m] * HW * C + q * CQ;
+    int foff[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int p = min(wbase + t * 16 + l15, HW - 1), h = p / W, wq = p - h * W;
+        foff[t] = (flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+    }
+    const int pix0 = wbase + lane * 4;
+    const bool live = pix0 < HW;
+    int nbad = 0;
+    for (int s = 0; s < S; ++s) {
+        frag_t wa[2][3];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int cls = min(ct * 16 + l15, K - 1);
+                frag_t v = *reinterpret_cast<const frag_t*>(wp + ((size_t)(s * 3 + p) * K + cls) * CP + q * CQ);
+                if (ct * 16 + l15 >= K)
+#pragma unroll
+                    for (int e = 0; e < (int)(sizeof(frag_t) / 2); ++e) v[e] = (__bf16)0.f;
+                wa[ct][p] = v;
+            }
+        float z[4][K];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) {
+                const frag_t fb = *reinterpret_cast<const frag_t*>(fs + foff[half * 8 + t8]);
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 2; p >= 0; --p) {   // smallest plane first
+                    a0 = HeadFrag<C>::mma(wa[0][p], fb, a0);
+                    a1 = HeadFrag<C>::mma(wa[1][p], fb, a1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ztw[(4 * q + r) * ZS + t8 * 16 + l15] = a0[r];
+                if (q == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ztw[(16 + r) * ZS + t8 * 16 + l15] = a1[r];
+            }
+            __builtin_amdgcn_wave_barrier();   // a wave's LDS traffic is in order: no workgroup barrier, only no reordering
+            if ((lane >> 5) == half) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(ztw + k * ZS + 4 * (lane & 31));
+                    z[0][k] = v.x, z[1][k] = v.y, z[2][k] = v.z, z[3][k] = v.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float bv = b[s * K + k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j][k] += bv;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float mx = -3.4e38f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, z[j][k]);
+            const float sc2 = invT * 1.4426950408889634f, off2 = -mx * sc2;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                z[j][k] = __builtin_amdgcn_exp2f(fmaf(z[j][k], sc2, off2));
+                sum += z[j][k];
+            }
+            const float inv = 1.0f / sum;
+            float ps = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                z[j][k] *= inv;
+                ps += z[j][k];
+            }
+            nbad += !(fabsf(ps - 1.f) <= tol);
+        }
+        if (live) {
+            float* out = prob + (((size_t)s * M + m) * K) * HW + pix0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(out + (size_t)k * HW) = make_float4(z[0][k], z[1][k], z[2][k], z[3][k]);
+        }
+    }
+    if (viol && live && nbad) atomicAdd(viol, nbad);
+}
+
 // Backward pass A: dz = p*(g - <g,p>)/T  (written to ws, same [S][M][K][H][W] layout) and
 // gfeat[src[m]][flip(h,w)][c] += sum_{s,k} W[s][k][c] dz[s][k].
 template <typename T>
@@ -607,6 +741,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 using namespace miseg;
 
+template <int C> static size_t head_mfma_lds(int64_t S) { return (size_t)(kHT / 64) * 20 * kHeadZS * 4 + (size_t)S * 3 * 20 * head_mfma_cp<C>() * 2; }
+// MISEG_HEAD_FWD_VALU=1 keeps the register (VALU) kernel for the shipped shapes: the A/B switch of DESIGN.md section 7
+static bool head_fwd_mfma_off() {
+    static const bool off = [] { const char* e = getenv("MISEG_HEAD_FWD_VALU"); return e && e[0] == '1'; }();
+    return off;
+}
+
 extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
                                     int64_t K, float T, float* prob, float simplex_tol, int32_t* simplex_violations) {
@@ -616,6 +757,15 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
     dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
     size_t ldsb = (size_t)K * kHT * 4;
     hipStream_t st = as_stream(stream);
+    if (dt == MISEG_BF16 && K == 20 && (C == 16 || C == 32) && (H * W) % 4 == 0 && S * K * C <= 3200 && !head_fwd_mfma_off()) {
+        const dim3 gridm((unsigned)cdiv(H * W, kHT * 4), (unsigned)M);
+        if (C == 32)
+            hipLaunchKernelGGL(head_local_fwd_mfma_kernel<32>, gridm, dim3(kHT), head_mfma_lds<32>(S), st, (const bf16*)feat, (int)H, (int)W,
+                               src, flips, (int)M, w, b, (int)S, 1.0f / T, prob, simplex_tol, simplex_violations);
+        else
+            hipLaunchKernelGGL(head_local_fwd_mfma_kernel<16>, gridm, dim3(kHT), head_mfma_lds<16>(S), st, (const bf16*)feat, (int)H, (int)W,
+                               src, flips, (int)M, w, b, (int)S, 1.0f / T, prob, simplex_tol, simplex_violations);
+    } else
     if (K <= 32 && (dt == MISEG_F32 || dt == MISEG_BF16)) {
         const bool quad = (H * W) % 4 == 0 && W % 4 == 0;
         const dim3 gridq((unsigned)cdiv(H * W, kHT * 4), (unsigned)M);

@@ -323,6 +323,32 @@ def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch):
     np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=0, atol=2e-4 * gscale)
 
 
+@pytest.mark.parametrize("c,h,w", [(32, 40, 48), (16, 6, 10), (16, 72, 36)])
+def test_local_head_forward_mfma_vs_float64(c, h, w):
+    """The shipped taps (bf16 features, S=5 x K=20, C in {16, 32}) compute the logits on the matrix pipe with the fp32
+    weights split into three bf16 planes (heads.hip: head_local_fwd_mfma_kernel).  Against a float64 evaluation of
+    softmax((W f + b) / T) on the gathered / flipped features (ref contrastyou/trainer/_utils.py:137-168,
+    semi_seg/epocher.py:258-273): 1e-5 relative on the probabilities, the same bound as the fp32 register kernel.
+    Shapes: a ragged tail (HW % 1024 != 0), W % 4 != 0, and several blocks per sample."""
+    torch.manual_seed(11)
+    feat = torch.randn(5, c, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(5, 20, c, device=DEV) * 0.7
+    b = torch.randn(5, 20, device=DEV)
+    src = torch.tensor([4, 0, 2, 1], dtype=torch.int32, device=DEV)
+    flips = torch.tensor([3, 0, 1, 2], dtype=torch.int32, device=DEV)
+    temp = 0.8
+    prob = ops().local_head(feat, wt, b, src, flips, temp)
+    from miseg_amd import checks
+    assert int(checks.simplex_violations(prob, 2)) == 0
+    g = feat.double()[src.long()]
+    g = torch.stack([gi.flip([d for d, on in ((1, f & 1), (2, f & 2)) if on]) if f else gi for gi, f in zip(g, flips.tolist())])
+    z = torch.einsum("skc,mchw->smkhw", wt.double(), g) + b.double()[:, None, :, None, None]
+    ref = torch.softmax(z / temp, dim=2)
+    assert prob.shape == ref.shape
+    assert float(((prob.double() - ref).abs() / (ref + 1e-9)).max()) <= 1e-5
+    assert float((prob.double() - ref).abs().max()) <= 2e-6
+
+
 @pytest.mark.parametrize("c,h", [(32, 40), (16, 24)])
 def test_local_head_backward_shipped_shape_bf16_vs_fp32_kernels(c, h):
     """S=5 x K=20 heads on bf16 features (the shipped taps).  C=32 takes the bf16-MFMA backward (dz as hi+lo bf16 planes, W^T
