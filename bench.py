@@ -71,8 +71,8 @@ def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
 
 
 class StepDriver:
-    """Runs UDAIICEpocher steps exactly as ``_run`` does (same code path, incl. the per-iteration meter sync),
-    but under external timing."""
+    """Runs UDAIICEpocher steps exactly as ``_run`` does (same code path, incl. the per-iteration meter read-back, which
+    -- as in ``_run`` -- is taken after the next iteration is enqueued), but under external timing."""
 
     def __init__(self, ep):
         from semi_seg._utils import FeatureExtractor
@@ -86,10 +86,10 @@ class StepDriver:
 
     def step(self):
         ep = self.ep
-        inter, union, grp = ep._step(next(ep._labeled_loader), next(ep._unlabeled_loader))
-        ep._record(ep._pending.fetch(), inter, union, grp)
+        ep._after_step(*ep._step(next(ep._labeled_loader), next(ep._unlabeled_loader)))
 
     def close(self):
+        self.ep._flush_records()
         self._fx.__exit__(None, None, None)
 
 
@@ -288,7 +288,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
-    t_host = time.perf_counter() - t0   # host-side enqueue time (each step ends with one blocking scalar fetch)
+    t_host = time.perf_counter() - t0   # host-side loop time (each step waits for the PREVIOUS step's scalars, so it tracks the GPU)
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed {args.steps} steps in {dt:.3f} s (host loop {t_host:.3f} s)")
