@@ -733,6 +733,196 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
     } else if (tid < R) out[R * C + tid] = gbacc;
 }
 
+// Wave-local backward of the local head for the shipped 16-channel tap (bf16 features, K = 20, S <= 5).  The fused kernel above
+// works a 64-pixel chunk per BLOCK through three phases with workgroup barriers between them; here every WAVE owns its chunks
+// outright and nothing but its own LDS slice is shared, so there is no barrier in the loop (a wave's LDS traffic is in order):
+//   per sub-head: p, g of the lane's pixel (coalesced along pixels) -> dz = p (g - <g,p>) / T in registers -> hi + lo bf16 planes,
+//                 written twice to the wave's LDS: [px][k] rows (operand of gfeat) and [k][px] rows (operand of gw, gb);
+//   gfeat^T[c][px] += W^T[c][k] dz^T[k][px]   3 x mfma_16x16x32_bf16 per 16-pixel tile (W_lo dz_hi + W_hi dz_lo + W_hi dz_hi)
+//   gw[k][c]       += dz^T[k][px] f[px][c]    2 per (32-pixel k-chunk, class tile): dz_lo f + dz_hi f (features are exact bf16)
+//   gb[k]          += dz^T[k][px] 1           the same A fragments against a constant all-ones B fragment
+// gw / gb stay in accumulators over all the wave's chunks; one deterministic partial per block at the end (same workspace and
+// final reduction as the fused kernel).  Precision is the fused BF variant's: hi + lo = 2^-16 relative per term.
+template <int C>
+__global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16* __restrict__ feat, int H, int W,
+                                                                     const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
+                                                                     int M, const float* __restrict__ w, int S, float invT,
+                                                                     const float* __restrict__ prob, const float* __restrict__ gprob,
+                                                                     bf16* __restrict__ gfeat, float* __restrict__ partials) {
+    constexpr int K = 20, SM = 5, CT = C / 16, AR = 24, BR = 72;
+    constexpr int WAVE_LDS = (2 * 64 * AR + 2 * K * BR + C * BR) * 2;   // bytes per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char hb[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    unsigned short* dzA = reinterpret_cast<unsigned short*>(hb + (size_t)wv * WAVE_LDS);   // [2][64][AR]  hi | lo, row = pixel
+    unsigned short* dzB = dzA + 2 * 64 * AR;                                               // [2][K][BR]   hi | lo, row = class
+    unsigned short* fT = dzB + 2 * K * BR;                                                 // [C][BR]      features, row = channel
+    unsigned short* wT = reinterpret_cast<unsigned short*>(hb + (size_t)4 * WAVE_LDS);     // [S][2][C][32] W^T hi | lo, classes >= K zero
+    const int HW = H * W, R = S * K;
+    for (int i = lane; i < 2 * 64 * AR / 2; i += 64) reinterpret_cast<unsigned*>(dzA)[i] = 0u;   // the pad columns 20..23 stay zero
+    for (int i = tid; i < S * 2 * C * 32; i += 256) {
+        const int k = i & 31, c = (i >> 5) % C, pl = (i / (32 * C)) & 1, s = i / (64 * C);
+        const float v = k < K ? w[((size_t)s * K + k) * C + c] : 0.f;
+        const unsigned short hi = f32_to_bf16_bits(v);
+        wT[i] = pl ? f32_to_bf16_bits(v - bf16_bits_to_f32(hi)) : hi;
+    }
+    __syncthreads();
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 agw[SM][2][CT], agb[SM][2];
+#pragma unroll
+    for (int s = 0; s < SM; ++s)
+#pragma unroll
+        for (int cl = 0; cl < 2; ++cl) {
+            agb[s][cl] = zero4;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) agw[s][cl][ct] = zero4;
+        }
+    bf16x8h_t ones, zfrag;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f, zfrag[e] = (__bf16)0.0f;
+    const int cps = (HW + 63) / 64, total = M * cps, nw = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wv; g < total; g += nw) {
+        const int m = g / cps, px0 = (g - m * cps) * 64;
+        const int f = flips ? flips[m] : 0;
+        const int px = px0 + lane, pc = min(px, HW - 1);
+        const bool live = px < HW;
+        const size_t sbase = (size_t)src[m] * HW;
+        {
+            const int h = pc / W, wq = pc - h * W;
+            const bf16* fp = feat + (sbase + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+#pragma unroll
+            for (int c0 = 0; c0 < C; c0 += 8) {
+                const s16x8 v = *reinterpret_cast<const s16x8*>(fp + c0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fT[(c0 + e) * BR + lane] = (unsigned short)v[e];
+            }
+        }
+        f32x4 agf[4][CT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) agf[t][ct] = zero4;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            if (s < S) {
+                const float* pp = prob + (((size_t)s * M + m) * K) * HW + pc;
+                const float* gq = gprob + (((size_t)s * M + m) * K) * HW + pc;
+                float p[K], gg[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) p[k] = pp[(size_t)k * HW], gg[k] = gq[(size_t)k * HW];
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) dot = fmaf(gg[k], p[k], dot);
+                unsigned short hi[K + 4], lo[K + 4];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float dz = live ? p[k] * (gg[k] - dot) * invT : 0.f;
+                    hi[k] = f32_to_bf16_bits(dz);
+                    lo[k] = f32_to_bf16_bits(dz - bf16_bits_to_f32(hi[k]));
+                    dzB[k * BR + lane] = hi[k];
+                    dzB[(K + k) * BR + lane] = lo[k];
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const unsigned short* v = pl ? lo : hi;
+                    s16x8 v0, v1;
+                    s16x4 v2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v0[e] = (short)v[e], v1[e] = (short)v[8 + e];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v2[e] = (short)v[16 + e];
+                    unsigned short* row = dzA + (pl * 64 + lane) * AR;
+                    *reinterpret_cast<s16x8*>(row) = v0;
+                    *reinterpret_cast<s16x8*>(row + 8) = v1;
+                    *reinterpret_cast<s16x4*>(row + 16) = v2;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // gfeat^T tiles: A = W^T [c][k], B = dz^T [k][px]
+                bf16x8h_t wh[CT], wl[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    wh[ct] = *reinterpret_cast<const bf16x8h_t*>(wT + ((size_t)(s * 2 + 0) * C + ct * 16 + l15) * 32 + 8 * q);
+                    wl[ct] = *reinterpret_cast<const bf16x8h_t*>(wT + ((size_t)(s * 2 + 1) * C + ct * 16 + l15) * 32 + 8 * q);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bf16x8h_t bh = *reinterpret_cast<const bf16x8h_t*>(dzA + (t * 16 + l15) * AR + 8 * min(q, 2));
+                    bf16x8h_t bl = *reinterpret_cast<const bf16x8h_t*>(dzA + (64 + t * 16 + l15) * AR + 8 * min(q, 2));
+                    if (q == 3) bh = zfrag, bl = zfrag;   // classes 24..31: no such columns in the row
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        agf[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ct], bh, agf[t][ct], 0, 0, 0);
+                        agf[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], bl, agf[t][ct], 0, 0, 0);
+                        agf[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], bh, agf[t][ct], 0, 0, 0);
+                    }
+                }
+                // gw, gb: A = dz^T [k][px], B = f [px][c] (or ones)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                    for (int cl = 0; cl < 2; ++cl) {
+                        const int k = cl * 16 + l15, kk = min(k, K - 1);
+                        bf16x8h_t ah = *reinterpret_cast<const bf16x8h_t*>(dzB + kk * BR + kc * 32 + 8 * q);
+                        bf16x8h_t al = *reinterpret_cast<const bf16x8h_t*>(dzB + (K + kk) * BR + kc * 32 + 8 * q);
+                        if (k >= K) ah = zfrag, al = zfrag;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            const bf16x8h_t fb = *reinterpret_cast<const bf16x8h_t*>(fT + (ct * 16 + l15) * BR + kc * 32 + 8 * q);
+                            agw[s][cl][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, fb, agw[s][cl][ct], 0, 0, 0);
+                            agw[s][cl][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, fb, agw[s][cl][ct], 0, 0, 0);
+                        }
+                        agb[s][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, agb[s][cl], 0, 0, 0);
+                        agb[s][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, agb[s][cl], 0, 0, 0);
+                    }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (gfeat) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pt = px0 + t * 16 + l15;
+                if (pt < HW) {
+                    const int h = pt / W, wq = pt - h * W;
+                    bf16* gp = gfeat + (sbase + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        s16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16_bits(agf[t][ct][r]);
+                        *reinterpret_cast<s16x4*>(gp + ct * 16 + 4 * q) = o;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // one partial per block: the four waves' accumulators through LDS, summed in wave order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(hb + (size_t)wv * WAVE_LDS);
+    const int len = R * C + R;
+    for (int i = lane; i < len; i += 64) red[i] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < SM; ++s)
+#pragma unroll
+        for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = cl * 16 + 4 * q + r;
+                if (s < S && k < K) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) red[(s * K + k) * C + ct * 16 + l15] = agw[s][cl][ct][r];
+                    if (l15 == 0) red[R * C + s * K + k] = agb[s][cl][r];
+                }
+            }
+    __syncthreads();
+    for (int i = tid; i < len; i += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) a += reinterpret_cast<const float*>(hb + (size_t)x * WAVE_LDS)[i];
+        partials[(size_t)blockIdx.x * len + i] = a;
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ out) {
     reduce_partials_block(partials, nparts, (size_t)len, len, out, [](int e) { return (size_t)e; });
 }
@@ -793,6 +983,12 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
     return MISEG_OK;
 }
 
+// MISEG_HEAD_BWD_FUSED=1 keeps the block-phased kernel for the 16-channel tap (A/B switch)
+static bool head_bwd_wave_off() {
+    static const bool off = [] { const char* e = getenv("MISEG_HEAD_BWD_FUSED"); return e && e[0] == '1'; }();
+    return off;
+}
+
 static int head_w_blocks(int64_t M, int64_t HW) { return (int)std::min<int64_t>(M * cdiv(HW, 64), 768); }
 
 extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K) {
@@ -816,6 +1012,13 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
         lds = std::max(lds, ((size_t)2 * 128 * 72 + cp * 72 + 2 * cp * 136) * 2 + (size_t)4 * 5 * 64 * 4);
     }
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
+    if (dt == MISEG_BF16 && K == 20 && C == 16 && S <= 5 && !head_bwd_wave_off()) {
+        constexpr int wave_lds = (2 * 64 * 24 + 2 * 20 * 72 + 16 * 72) * 2;
+        const size_t wl = (size_t)4 * wave_lds + (size_t)S * 2 * 16 * 32 * 2;
+        hipFuncSetAttribute((const void*)head_local_bwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+        hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nblk), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
+                           (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials);
+    } else
 #define HLB2(TT, CTM, RW, K20V, BFV)                                                                                                         \
     {                                                                                                                             \
         hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW, K20V, BFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

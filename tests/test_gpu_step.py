@@ -143,6 +143,31 @@ def test_first_iteration_is_tight(golden, mode):
             np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
 
 
+def test_deferred_readback_records_every_iteration_like_the_synchronous_one():
+    """The loop reads iteration i's scalars and Dice counts after iteration i+1 is enqueued (pinned ring, semi_seg/epocher.py
+    `_after_step`).  An epoch must give exactly the meters of the per-iteration read-back (MISEG_DEFER_FETCH=0 behaviour), and
+    a NaN loss must still end the epoch with the reference's RuntimeError (ref semi_seg/epocher.py:129-130)."""
+    from semi_seg.epocher import UDAIICEpocher
+    results = []
+    for defer in (True, False):
+        model, pw, lw, opt, lab, unl, kl = build("udaiic")
+        random.seed(99)
+        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=STEP["NB"], cur_epoch=0, device=DEV,
+                           feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1)
+        ep._DEFER_FETCH = defer
+        results.append((repr(dict(ep.run())), opt.flat.flat_param.detach().clone()))
+        assert ep._inflight is None
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
+    model, pw, lw, opt, lab, unl, kl = build("udaiic")
+    with torch.no_grad():
+        list(pw.parameters())[-1].fill_(float("nan"))   # a head bias: every probability of that tap is NaN -> not a simplex
+    ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=STEP["NB"], cur_epoch=0, device=DEV,
+                       feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1)
+    with pytest.raises((RuntimeError, AssertionError)):
+        ep.run()
+
+
 def test_step_graph_replay_equals_eager_steps():
     """The captured hipGraph of the device half of an iteration (miseg_amd.graph.StepGraph) must reproduce the eager
     iterations: same meters and bit-identical parameters after a mix of eager warm-up, capture and replays.
