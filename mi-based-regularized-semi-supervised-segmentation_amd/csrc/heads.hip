@@ -733,6 +733,9 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
     } else if (tid < R) out[R * C + tid] = gbacc;
 }
 
+#ifndef MISEG_HB_ABL
+#define MISEG_HB_ABL 0   // timing ablations of head_local_bwd_wave_kernel (scratch builds only): 1 no gw/gb, 2 no gfeat, 3 no MFMA phase, 4 no [k][px] dz writes, 5 = 3 + 4
+#endif
 // Wave-local backward of the local head for the shipped 16-channel tap (bf16 features, K = 20, S <= 5).  The fused kernel above
 // works a 64-pixel chunk per BLOCK through three phases with workgroup barriers between them; here every WAVE owns its chunks
 // outright and nothing but its own LDS slice is shared, so there is no barrier in the loop (a wave's LDS traffic is in order):
@@ -780,8 +783,18 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f, zfrag[e] = (__bf16)0.0f;
     const int cps = (HW + 63) / 64, total = M * cps, nw = gridDim.x * 4;
+    // p, g of the NEXT (chunk, sub-head) are fetched while the current one is worked on: P/G[s & 1] is sub-head s's buffer
+    // (S = 5 is odd, so the buffer a chunk ends on is copied down once per chunk)
+    float P[2][K], G[2][K];
+    {
+        const int g0 = min(blockIdx.x * 4 + wv, total - 1), m0 = g0 / cps, pc0 = min((g0 - m0 * cps) * 64 + lane, HW - 1);
+        const size_t o = ((size_t)m0 * K) * HW + pc0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) P[0][k] = prob[o + (size_t)k * HW], G[0][k] = gprob[o + (size_t)k * HW];
+    }
     for (int g = blockIdx.x * 4 + wv; g < total; g += nw) {
         const int m = g / cps, px0 = (g - m * cps) * 64;
+        const int gn = min(g + nw, total - 1), mn = gn / cps, pcn = min((gn - mn * cps) * 64 + lane, HW - 1);
         const int f = flips ? flips[m] : 0;
         const int px = px0 + lane, pc = min(px, HW - 1);
         const bool live = px < HW;
@@ -803,40 +816,46 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
             for (int ct = 0; ct < CT; ++ct) agf[t][ct] = zero4;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            if (s < S) {
-                const float* pp = prob + (((size_t)s * M + m) * K) * HW + pc;
-                const float* gq = gprob + (((size_t)s * M + m) * K) * HW + pc;
-                float p[K], gg[K];
+            {   // S == SM: the launcher takes this kernel for five sub-heads only, so the loop is straight-line code
+                {
+                    const size_t o = s + 1 < SM ? (((size_t)(s + 1) * M + m) * K) * HW + pc : ((size_t)mn * K) * HW + pcn;
 #pragma unroll
-                for (int k = 0; k < K; ++k) p[k] = pp[(size_t)k * HW], gg[k] = gq[(size_t)k * HW];
+                    for (int k = 0; k < K; ++k) P[(s + 1) & 1][k] = prob[o + (size_t)k * HW], G[(s + 1) & 1][k] = gprob[o + (size_t)k * HW];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float* p = P[s & 1];
+                const float* gg = G[s & 1];
                 float dot = 0.f;
 #pragma unroll
                 for (int k = 0; k < K; ++k) dot = fmaf(gg[k], p[k], dot);
-                unsigned short hi[K + 4], lo[K + 4];
+                unsigned hw[K / 2], lw[K / 2];   // bf16 pairs (classes 2i, 2i+1): hi plane, lo plane
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float dz = live ? p[k] * (gg[k] - dot) * invT : 0.f;
-                    hi[k] = f32_to_bf16_bits(dz);
-                    lo[k] = f32_to_bf16_bits(dz - bf16_bits_to_f32(hi[k]));
-                    dzB[k * BR + lane] = hi[k];
-                    dzB[(K + k) * BR + lane] = lo[k];
+                for (int k = 0; k < K; k += 2) {
+                    unsigned short h2[2], l2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float dz = live ? p[k + e] * (gg[k + e] - dot) * invT : 0.f;
+                        h2[e] = f32_to_bf16_bits(dz);
+                        l2[e] = f32_to_bf16_bits(dz - bf16_bits_to_f32(h2[e]));
+#if MISEG_HB_ABL != 4 && MISEG_HB_ABL != 5
+                        dzB[(k + e) * BR + lane] = h2[e];
+                        dzB[(K + k + e) * BR + lane] = l2[e];
+#endif
+                    }
+                    hw[k / 2] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
+                    lw[k / 2] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
                 }
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    const unsigned short* v = pl ? lo : hi;
-                    s16x8 v0, v1;
-                    s16x4 v2;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v0[e] = (short)v[e], v1[e] = (short)v[8 + e];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v2[e] = (short)v[16 + e];
-                    unsigned short* row = dzA + (pl * 64 + lane) * AR;
-                    *reinterpret_cast<s16x8*>(row) = v0;
-                    *reinterpret_cast<s16x8*>(row + 8) = v1;
-                    *reinterpret_cast<s16x4*>(row + 16) = v2;
+                    const unsigned* v = pl ? lw : hw;
+                    unsigned* row = reinterpret_cast<unsigned*>(dzA + (pl * 64 + lane) * AR);
+                    *reinterpret_cast<uint4*>(row) = make_uint4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<uint4*>(row + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+                    *reinterpret_cast<uint2*>(row + 8) = make_uint2(v[8], v[9]);
                 }
                 __builtin_amdgcn_wave_barrier();
                 // gfeat^T tiles: A = W^T [c][k], B = dz^T [k][px]
+#if MISEG_HB_ABL != 2 && MISEG_HB_ABL != 3 && MISEG_HB_ABL != 5
                 bf16x8h_t wh[CT], wl[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -855,6 +874,8 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                         agf[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ct], bh, agf[t][ct], 0, 0, 0);
                     }
                 }
+#endif
+#if MISEG_HB_ABL != 1 && MISEG_HB_ABL != 3 && MISEG_HB_ABL != 5
                 // gw, gb: A = dz^T [k][px], B = f [px][c] (or ones)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc)
@@ -873,6 +894,7 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                         agb[s][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ones, agb[s][cl], 0, 0, 0);
                         agb[s][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ones, agb[s][cl], 0, 0, 0);
                     }
+#endif
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -894,6 +916,8 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
             }
         }
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < K; ++k) P[0][k] = P[SM & 1][k], G[0][k] = G[SM & 1][k];
     }
     // one partial per block: the four waves' accumulators through LDS, summed in wave order
     __syncthreads();
@@ -908,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = cl * 16 + 4 * q + r;
-                if (s < S && k < K) {
+                if (k < K) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) red[(s * K + k) * C + ct * 16 + l15] = agw[s][cl][ct][r];
                     if (l15 == 0) red[R * C + s * K + k] = agb[s][cl][r];
@@ -1012,11 +1036,17 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
         lds = std::max(lds, ((size_t)2 * 128 * 72 + cp * 72 + 2 * cp * 136) * 2 + (size_t)4 * 5 * 64 * 4);
     }
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
-    if (dt == MISEG_BF16 && K == 20 && C == 16 && S <= 5 && !head_bwd_wave_off()) {
+    if (dt == MISEG_BF16 && K == 20 && C == 16 && S == 5 && !head_bwd_wave_off()) {
         constexpr int wave_lds = (2 * 64 * 24 + 2 * 20 * 72 + 16 * 72) * 2;
         const size_t wl = (size_t)4 * wave_lds + (size_t)S * 2 * 16 * 32 * 2;
         hipFuncSetAttribute((const void*)head_local_bwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
-        hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nblk), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
+        // one block per CU: alone the kernel runs as fast with 256 blocks as with 768 (it is bound by the p / g read pattern, 256 B
+        // per plane and wave, not by occupancy -- DESIGN.md section 7), and the smaller footprint leaves LDS and registers to the
+        // main-stream kernels this side-stream kernel runs next to.  MISEG_HEAD_BWD_BLOCKS overrides (A/B runs).
+        static const int cap = [] { const char* e = getenv("MISEG_HEAD_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
+        const int nb = cap > 0 ? std::min(cap, nblk) : nblk;
+        if (nb < nblk) hipMemsetAsync(partials + (size_t)nb * (R * C + R), 0, (size_t)(nblk - nb) * (R * C + R) * 4, st);
+        hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nb), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
                            (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials);
     } else
 #define HLB2(TT, CTM, RW, K20V, BFV)                                                                                                         \
