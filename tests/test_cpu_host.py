@@ -245,3 +245,37 @@ def test_surface_meter_hausdorff_against_brute_force():
     with pytest.raises(RuntimeError):                      # an absent class aborts the batch, as MedPy does
         m.add(torch.zeros(1, 8, 8, dtype=torch.int64), tgt[:1, :8, :8])
     assert m._n == 1
+
+
+def test_deferred_readback_ticket_order_and_flush():
+    """Host logic of the one-iteration-late read-back (semi_seg/epocher.py `_Pending.post` / `wait`, `TrainEpocher._after_step`):
+    iteration i is recorded when iteration i+1 posts, the last one by `_flush_records`, every iteration exactly once and in
+    order, with the Dice counts of ITS iteration; MISEG_DEFER_FETCH=0 semantics (`_DEFER_FETCH = False`) record immediately.
+    CPU tensors take the synchronous branch of `post`, so this runs without a GPU."""
+    from semi_seg.epocher import TrainEpocher, _Pending
+
+    class Probe(TrainEpocher):
+        def __init__(self, defer):   # noqa: the loop helpers only need these three attributes
+            self._pending, self._inflight, self._DEFER_FETCH, self.seen = _Pending(), None, defer, []
+
+        def _record(self, host, inter, union, label_group):
+            self.seen.append((host["sup_loss"], int(inter.sum()), int(union.sum()), label_group))
+
+    for defer in (True, False):
+        ep = Probe(defer)
+        for i in range(4):
+            ep._pending.put("sup_loss", torch.tensor(float(i)))
+            ep._pending.put("reg_loss", torch.tensor(0.5))
+            ep._after_step(torch.full((2, 3), i), torch.full((2, 3), 10 * i), f"g{i}")
+            assert len(ep.seen) == (i if defer else i + 1)
+        ep._flush_records()
+        ep._flush_records()   # idempotent
+        assert ep.seen == [(float(i), 6 * i, 60 * i, f"g{i}") for i in range(4)]
+    # a failed deferred assertion surfaces from wait(), i.e. one iteration late but never lost
+    from miseg_amd import checks
+    pend = _Pending()
+    with checks.deferred(pend.checks):
+        checks.require_zero(torch.tensor(3), AssertionError, "three bad pixels")
+    ticket = pend.post()
+    with pytest.raises(AssertionError, match="three bad pixels"):
+        _Pending.wait(ticket)
