@@ -72,6 +72,12 @@ int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, cons
                               float* raw, void* ws, int64_t ws_bytes, int precision);
 int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
                              float* loss, float* grad_raw);
+/* The same epilogue with one block per (window, displacement) instead of one block per window -- same numbers for grad_raw,
+ * loss summed over the displacements in d order -- for paddings whose (2 pad + 1)^2 displacements would take the single block
+ * several rounds (pad >= 2).  ws: miseg_iic_local_loss_ws_bytes(pad, P) bytes (the per-displacement loss terms). */
+int64_t miseg_iic_local_loss_ws_bytes(int64_t pad, int64_t P);
+int miseg_iic_local_loss_fwd_ws(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
+                                float* loss, float* grad_raw, void* ws, int64_t ws_bytes);
 int miseg_iic_local_bwd(void* stream, const float* x, const float* y, const float* mask, int64_t N, int64_t K,
                         int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
                         const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate, int precision,

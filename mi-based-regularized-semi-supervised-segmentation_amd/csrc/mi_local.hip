@@ -164,6 +164,73 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const float* __restri
 // -------------------------------------------------------------------------------------------
 // Epilogue: one block per window.  fp32 throughout, same operation order as iic_loss.py:124-146.
 // -------------------------------------------------------------------------------------------
+// One displacement d of one window, worked by ONE wave (both loss kernels call this, so their numbers are identical): normalise
+// (R - mn + eps), symmetrise, marginals, the displacement's loss term (returned) and d loss / d raw[d] (written to grad_d).
+__device__ __forceinline__ float loss_displacement(const float* __restrict__ R, float mn, int K, int TT, float lamda, float* Pw,
+                                                   float* Gw, float* colv, float* rowv, float* __restrict__ grad_d, int lane) {
+    const int KK = K * K;
+    const float eps = 1e-16f;
+    float z = 0.f;
+    for (int e = lane; e < KK; e += 64) z += (R[e] - mn) + eps;
+    z = wave_sum(z);
+    for (int e = lane; e < KK; e += 64) {
+        int i = e / K, j = e % K;
+        float q = ((R[e] - mn) + eps) / z, qt = ((R[j * K + i] - mn) + eps) / z;
+        Pw[e] = (q + qt) / 2.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // the marginals' logarithms and ratios depend on one index only: evaluated once per class (2K logf instead of 2K^2;
+    // same operands, same results), lanes [0,K) the column side, lanes [32,32+K) the row side when K <= 32
+    if (K <= 32) {
+        const int c = lane & 31;
+        if (c < K) {
+            float v = 0.f;
+            if (lane < 32) { for (int t = 0; t < K; ++t) v += Pw[t * K + c]; }   // p_i_mat: sum over dim i, a function of j (iic_loss.py:135)
+            else { for (int t = 0; t < K; ++t) v += Pw[c * K + t]; }             // p_j_mat: sum over dim j, a function of i (iic_loss.py:136)
+            float* o = lane < 32 ? colv : rowv;
+            o[c] = logf(v + eps);
+            o[2 * K + c] = v / (v + eps);
+        }
+    } else {
+        for (int c = lane; c < K; c += 64) {
+            float cs = 0.f, rs = 0.f;
+            for (int t = 0; t < K; ++t) { cs += Pw[t * K + c]; rs += Pw[c * K + t]; }
+            colv[c] = logf(cs + eps), colv[2 * K + c] = cs / (cs + eps);
+            rowv[c] = logf(rs + eps), rowv[2 * K + c] = rs / (rs + eps);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    float part = 0.f;
+    for (int e = lane; e < KK; e += 64) {
+        int i = e / K, j = e % K;
+        float ps = Pw[e];
+        float lp = logf(ps + eps), lc = colv[j], lr = rowv[i];
+        part += ps * (lp - lamda * lc - lamda * lr);
+        Gw[e] = -(lp + ps / (ps + eps) - lamda * (lc + colv[2 * K + j]) - lamda * (lr + rowv[2 * K + i])) / (float)TT;
+    }
+    const float term = -wave_sum(part);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    float sdot = 0.f;
+    for (int e = lane; e < KK; e += 64) {
+        int i = e / K, j = e % K;
+        float gq = (Gw[e] + Gw[j * K + i]) / 2.0f;
+        float q = ((R[e] - mn) + eps) / z;
+        sdot += gq * q;
+    }
+    sdot = wave_sum(sdot);
+    for (int e = lane; e < KK; e += 64) {
+        int i = e / K, j = e % K;
+        float gq = (Gw[e] + Gw[j * K + i]) / 2.0f;
+        grad_d[e] = (gq - sdot) / z;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    return term;
+}
+
 __global__ __launch_bounds__(1024) void local_loss_kernel(const float* __restrict__ raw_all, int K, int T, float lamda,
                                                           float* __restrict__ loss, float* __restrict__ grad_all) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -175,76 +242,48 @@ __global__ __launch_bounds__(1024) void local_loss_kernel(const float* __restric
     float* Gw = Pw + KK;
     float* colv = Gw + KK;       // [0,K) log(colsum + eps), [2K,3K) colsum / (colsum + eps)
     float* rowv = colv + K;      // [K,2K) and [3K,4K): the same for the row sums
-    const float eps = 1e-16f;
-
     float mn = 3.4e38f;
     for (int e = threadIdx.x; e < TT * KK; e += blockDim.x) mn = fminf(mn, raw[e]);
     mn = block_min(mn, red);
 
     float wave_loss = 0.f;
     for (int d = wid; d < TT; d += nw) {
-        const float* R = raw + (size_t)d * KK;
-        float z = 0.f;
-        for (int e = lane; e < KK; e += 64) z += (R[e] - mn) + eps;
-        z = wave_sum(z);
-        for (int e = lane; e < KK; e += 64) {
-            int i = e / K, j = e % K;
-            float q = ((R[e] - mn) + eps) / z, qt = ((R[j * K + i] - mn) + eps) / z;
-            Pw[e] = (q + qt) / 2.0f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        // the marginals' logarithms and ratios depend on one index only: evaluated once per class (2K logf instead of 2K^2;
-        // same operands, same results), lanes [0,K) the column side, lanes [32,32+K) the row side when K <= 32
-        if (K <= 32) {
-            const int c = lane & 31;
-            if (c < K) {
-                float v = 0.f;
-                if (lane < 32) { for (int t = 0; t < K; ++t) v += Pw[t * K + c]; }   // p_i_mat: sum over dim i, a function of j (iic_loss.py:135)
-                else { for (int t = 0; t < K; ++t) v += Pw[c * K + t]; }             // p_j_mat: sum over dim j, a function of i (iic_loss.py:136)
-                float* o = lane < 32 ? colv : rowv;
-                o[c] = logf(v + eps);
-                o[2 * K + c] = v / (v + eps);
-            }
-        } else {
-            for (int c = lane; c < K; c += 64) {
-                float cs = 0.f, rs = 0.f;
-                for (int t = 0; t < K; ++t) { cs += Pw[t * K + c]; rs += Pw[c * K + t]; }
-                colv[c] = logf(cs + eps), colv[2 * K + c] = cs / (cs + eps);
-                rowv[c] = logf(rs + eps), rowv[2 * K + c] = rs / (rs + eps);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        float part = 0.f;
-        for (int e = lane; e < KK; e += 64) {
-            int i = e / K, j = e % K;
-            float ps = Pw[e];
-            float lp = logf(ps + eps), lc = colv[j], lr = rowv[i];
-            part += ps * (lp - lamda * lc - lamda * lr);
-            Gw[e] = -(lp + ps / (ps + eps) - lamda * (lc + colv[2 * K + j]) - lamda * (lr + rowv[2 * K + i])) / (float)TT;
-        }
-        wave_loss -= wave_sum(part);
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        float sdot = 0.f;
-        for (int e = lane; e < KK; e += 64) {
-            int i = e / K, j = e % K;
-            float gq = (Gw[e] + Gw[j * K + i]) / 2.0f;
-            float q = ((R[e] - mn) + eps) / z;
-            sdot += gq * q;
-        }
-        sdot = wave_sum(sdot);
-        for (int e = lane; e < KK; e += 64) {
-            int i = e / K, j = e % K;
-            float gq = (Gw[e] + Gw[j * K + i]) / 2.0f;
-            grad[(size_t)d * KK + e] = (gq - sdot) / z;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        wave_loss += loss_displacement(raw + (size_t)d * KK, mn, K, TT, lamda, Pw, Gw, colv, rowv, grad + (size_t)d * KK, lane);
     }
     float tot = block_sum(lane == 0 ? wave_loss : 0.f, red);
     if (threadIdx.x == 0) loss[blockIdx.x] = tot / (float)TT;
+}
+
+
+// The same epilogue with one block per (window, displacement): the single-block form walks its T^2 displacements in
+// ceil(T^2 / 16) rounds of ~12 us each on ONE CU while the IIC chain -- the step's critical path -- waits for it.  Every block
+// recomputes the window's global minimum (T^2 K^2 floats, L2-resident), wave 0 runs loss_displacement, the displacement's
+// loss term goes to parts[window][d]; local_loss_finish_kernel adds them up in d order.
+__global__ __launch_bounds__(256) void local_loss_disp_kernel(const float* __restrict__ raw_all, int K, int T, float lamda,
+                                                              float* __restrict__ parts, float* __restrict__ grad_all) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[17];
+    const int KK = K * K, TT = T * T, wid = threadIdx.x >> 6, lane = threadIdx.x & 63, d = blockIdx.y;
+    const float* raw = raw_all + (size_t)blockIdx.x * TT * KK;
+    float mn = 3.4e38f;
+    for (int e = threadIdx.x; e < TT * KK; e += blockDim.x) mn = fminf(mn, raw[e]);
+    mn = block_min(mn, red);
+    if (wid != 0) return;
+    float* Pw = sm;
+    float* Gw = Pw + KK;
+    float* colv = Gw + KK;
+    float* rowv = colv + K;
+    const float term = loss_displacement(raw + (size_t)d * KK, mn, K, TT, lamda, Pw, Gw, colv, rowv,
+                                         grad_all + ((size_t)blockIdx.x * TT + d) * KK, lane);
+    if (lane == 0) parts[(size_t)blockIdx.x * TT + d] = term;
+}
+
+__global__ __launch_bounds__(64) void local_loss_finish_kernel(const float* __restrict__ parts, int TT, float* __restrict__ loss) {
+    if (threadIdx.x != 0) return;
+    const float* p = parts + (size_t)blockIdx.x * TT;
+    float tot = 0.f;
+    for (int d = 0; d < TT; ++d) tot += p[d];
+    loss[blockIdx.x] = tot / (float)TT;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -672,6 +711,23 @@ extern "C" int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64
 
 extern "C" int64_t miseg_iic_local_bwd_ws_bytes(int64_t K, int64_t pad, int64_t P) {
     return (int64_t)local_bwd_bf16_ws_bytes(K, pad, P) + 16;
+}
+
+extern "C" int64_t miseg_iic_local_loss_ws_bytes(int64_t pad, int64_t P) { return P * (2 * pad + 1) * (2 * pad + 1) * 4; }
+
+extern "C" int miseg_iic_local_loss_fwd_ws(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
+                                           float* loss, float* grad_raw, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(raw && loss && grad_raw && ws, "iic_local_loss_fwd_ws: null pointer");
+    MISEG_REQUIRE(K > 0 && K <= 64 && pad >= 0 && P > 0, "iic_local_loss_fwd_ws: bad shape");
+    MISEG_REQUIRE(ws_bytes >= miseg_iic_local_loss_ws_bytes(pad, P), "iic_local_loss_fwd_ws: workspace too small");
+    const int T = 2 * (int)pad + 1;
+    const size_t ldsb = (size_t)(2 * K * K + 4 * K) * 4;
+    hipLaunchKernelGGL(local_loss_disp_kernel, dim3((unsigned)P, (unsigned)(T * T)), dim3(256), ldsb, as_stream(stream), raw, (int)K, T,
+                       lamda, (float*)ws, grad_raw);
+    MISEG_LAUNCH_CHECK("local_loss_disp_kernel");
+    hipLaunchKernelGGL(local_loss_finish_kernel, dim3((unsigned)P), dim3(64), 0, as_stream(stream), (const float*)ws, T * T, loss);
+    MISEG_LAUNCH_CHECK("local_loss_finish_kernel");
+    return MISEG_OK;
 }
 
 extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,

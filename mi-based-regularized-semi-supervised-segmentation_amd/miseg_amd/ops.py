@@ -143,7 +143,7 @@ class _LocalMI(torch.autograd.Function):
         _local_fwd(x, y, mask, pad, windows, win, raw)
         loss = torch.empty(p, dtype=torch.float32, device=dev)
         grad_raw = torch.empty_like(raw)
-        call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
+        _local_loss(raw, k, pad, p, lamda, loss, grad_raw)
         ctx.save_for_backward(x, y, mask, grad_raw, win)
         ctx.pad, ctx.windows = pad, list(windows)
         ctx.raw = raw
@@ -157,6 +157,16 @@ class _LocalMI(torch.autograd.Function):
         gx, gy = (torch.empty_like(x), torch.empty_like(y)) if whole else (torch.zeros_like(x), torch.zeros_like(y))
         _local_bwd(x, y, mask, ctx.pad, ctx.windows, win, grad_raw, gloss.contiguous().float(), gx, gy)
         return gx, gy, None, None, None, None
+
+
+def _local_loss(raw: Tensor, k: int, pad: int, p: int, lamda: float, loss: Tensor, grad_raw: Tensor) -> None:
+    """Loss epilogue of the local MI (ref iic_loss.py:124-146).  pad >= 2: one block per (window, displacement) -- the single
+    block per window needs ceil((2 pad + 1)^2 / 16) rounds on one CU while the IIC chain waits for it."""
+    if pad >= 2:
+        ws = _ws(query("miseg_iic_local_loss_ws_bytes", pad, p), raw.device)
+        call("miseg_iic_local_loss_fwd_ws", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw), _ptr(ws), ws.numel())
+    else:
+        call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
 
 
 class _LocalMIHeads(torch.autograd.Function):
@@ -187,7 +197,7 @@ class _LocalMIHeads(torch.autograd.Function):
                 _local_fwd(probs[i, :ub], probs[i, ub:], mask, pad, windows, win, raw[i])
         loss = torch.empty(s, p, dtype=torch.float32, device=dev)
         grad_raw = torch.empty_like(raw)
-        call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, s * p, float(lamda), _ptr(loss), _ptr(grad_raw))
+        _local_loss(raw, k, pad, s * p, lamda, loss, grad_raw)
         ctx.save_for_backward(probs, mask, grad_raw, win)
         ctx.pad, ctx.windows, ctx.ub = pad, list(windows), ub
         return loss

@@ -374,3 +374,30 @@ def test_local_head_backward_shipped_shape_bf16_vs_fp32_kernels(c, h):
         assert float((a16 - a32).abs().max()) <= 2e-4 * float(a32.abs().max())
     assert float((gf16 - gf32).abs().max()) <= 2.0 ** -7 * float(gf32.abs().max())
     assert float(gf32[0].abs().max()) == 0.0 and float(gf16[0].abs().max()) == 0.0      # untouched source rows stay zero
+
+
+@pytest.mark.parametrize("pad,p", [(3, 5), (2, 1), (1, 3)])
+def test_local_loss_per_displacement_blocks_equal_the_single_block_epilogue(pad, p):
+    """miseg_iic_local_loss_fwd_ws (one block per window and displacement, the form the IIC chain uses for pad >= 2) against
+    miseg_iic_local_loss_fwd (one block per window): both run the same per-displacement routine, so grad_raw must be
+    bit-identical; the loss differs only in the order its (2 pad + 1)^2 terms are added (1e-6 relative)."""
+    from miseg_amd import _cabi
+    k, t = 20, 2 * pad + 1
+    torch.manual_seed(5)
+    raw = torch.rand(p, t, t, k, k, device=DEV) * 3.0 + 0.01
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for ws_form in (False, True):
+        loss, grad = torch.empty(p, device=DEV), torch.empty_like(raw)
+        if ws_form:
+            nb = _cabi.query("miseg_iic_local_loss_ws_bytes", pad, p)
+            assert nb == p * t * t * 4
+            ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            _cabi.call("miseg_iic_local_loss_fwd_ws", st, raw.data_ptr(), k, pad, p, 1.0, loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), nb)
+            with pytest.raises(_cabi.MisegError):
+                _cabi.call("miseg_iic_local_loss_fwd_ws", st, raw.data_ptr(), k, pad, p, 1.0, loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), nb - 4)
+        else:
+            _cabi.call("miseg_iic_local_loss_fwd", st, raw.data_ptr(), k, pad, p, 1.0, loss.data_ptr(), grad.data_ptr())
+        outs.append((loss, grad))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-9)
