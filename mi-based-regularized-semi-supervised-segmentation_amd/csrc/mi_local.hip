@@ -166,10 +166,17 @@ __global__ __launch_bounds__(256) void joint_reduce_kernel(const float* __restri
 // -------------------------------------------------------------------------------------------
 // One displacement d of one window, worked by ONE wave (both loss kernels call this, so their numbers are identical): normalise
 // (R - mn + eps), symmetrise, marginals, the displacement's loss term (returned) and d loss / d raw[d] (written to grad_d).
-__device__ __forceinline__ float loss_displacement(const float* __restrict__ R, float mn, int K, int TT, float lamda, float* Pw,
+__device__ __forceinline__ float loss_displacement(const float* __restrict__ Rg, float mn, int K, int TT, float lamda, float* Pw,
                                                    float* Gw, float* colv, float* rowv, float* __restrict__ grad_d, int lane) {
     const int KK = K * K;
     const float eps = 1e-16f;
+    // the displacement's K x K joint is read three times, twice transposed: one coalesced pass into the wave's LDS slice first
+    // (independent loads, one L2 latency) instead of a dependent L2 round trip per later access
+    float* Rw = rowv + 3 * K;
+    for (int e = lane; e < KK; e += 64) Rw[e] = Rg[e];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const float* R = Rw;
     float z = 0.f;
     for (int e = lane; e < KK; e += 64) z += (R[e] - mn) + eps;
     z = wave_sum(z);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(1024) void local_loss_kernel(const float* __restric
     const int KK = K * K, TT = T * T, nw = blockDim.x >> 6, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* raw = raw_all + (size_t)blockIdx.x * TT * KK;
     float* grad = grad_all + (size_t)blockIdx.x * TT * KK;
-    float* Pw = sm + (size_t)wid * (2 * KK + 4 * K);  // per wave: Ps[KK], Gs[KK], col {log, ratio}[K, .., K], row {log, ratio}
+    float* Pw = sm + (size_t)wid * (3 * KK + 4 * K);  // per wave: Ps[KK], Gs[KK], col {log, ratio}[K, .., K], row {log, ratio}, R[KK]
     float* Gw = Pw + KK;
     float* colv = Gw + KK;       // [0,K) log(colsum + eps), [2K,3K) colsum / (colsum + eps)
     float* rowv = colv + K;      // [K,2K) and [3K,4K): the same for the row sums
@@ -259,14 +266,22 @@ __global__ __launch_bounds__(1024) void local_loss_kernel(const float* __restric
 // ceil(T^2 / 16) rounds of ~12 us each on ONE CU while the IIC chain -- the step's critical path -- waits for it.  Every block
 // recomputes the window's global minimum (T^2 K^2 floats, L2-resident), wave 0 runs loss_displacement, the displacement's
 // loss term goes to parts[window][d]; local_loss_finish_kernel adds them up in d order.
-__global__ __launch_bounds__(256) void local_loss_disp_kernel(const float* __restrict__ raw_all, int K, int T, float lamda,
+__global__ __launch_bounds__(1024) void local_loss_disp_kernel(const float* __restrict__ raw_all, int K, int T, float lamda,
                                                               float* __restrict__ parts, float* __restrict__ grad_all) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[17];
     const int KK = K * K, TT = T * T, wid = threadIdx.x >> 6, lane = threadIdx.x & 63, d = blockIdx.y;
     const float* raw = raw_all + (size_t)blockIdx.x * TT * KK;
     float mn = 3.4e38f;
-    for (int e = threadIdx.x; e < TT * KK; e += blockDim.x) mn = fminf(mn, raw[e]);
+    const int n = TT * KK;
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0) {   // 16-byte pieces: ~5 independent loads per thread
+        for (int e = threadIdx.x; e < n / 4; e += blockDim.x) {
+            const float4 v = reinterpret_cast<const float4*>(raw)[e];
+            mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
+        }
+    } else {
+        for (int e = threadIdx.x; e < n; e += blockDim.x) mn = fminf(mn, raw[e]);
+    }
     mn = block_min(mn, red);
     if (wid != 0) return;
     float* Pw = sm;
@@ -279,11 +294,15 @@ __global__ __launch_bounds__(256) void local_loss_disp_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(64) void local_loss_finish_kernel(const float* __restrict__ parts, int TT, float* __restrict__ loss) {
-    if (threadIdx.x != 0) return;
     const float* p = parts + (size_t)blockIdx.x * TT;
+    const int lane = threadIdx.x;
     float tot = 0.f;
-    for (int d = 0; d < TT; ++d) tot += p[d];
-    loss[blockIdx.x] = tot / (float)TT;
+    for (int d0 = 0; d0 < TT; d0 += 64) {   // one coalesced load per 64 terms, then the d-ordered sum out of registers
+        const float v = d0 + lane < TT ? p[d0 + lane] : 0.f;
+        const int m = min(64, TT - d0);
+        for (int d = 0; d < m; ++d) tot += __shfl(v, d, 64);
+    }
+    if (lane == 0) loss[blockIdx.x] = tot / (float)TT;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -721,8 +740,8 @@ extern "C" int miseg_iic_local_loss_fwd_ws(void* stream, const float* raw, int64
     MISEG_REQUIRE(K > 0 && K <= 64 && pad >= 0 && P > 0, "iic_local_loss_fwd_ws: bad shape");
     MISEG_REQUIRE(ws_bytes >= miseg_iic_local_loss_ws_bytes(pad, P), "iic_local_loss_fwd_ws: workspace too small");
     const int T = 2 * (int)pad + 1;
-    const size_t ldsb = (size_t)(2 * K * K + 4 * K) * 4;
-    hipLaunchKernelGGL(local_loss_disp_kernel, dim3((unsigned)P, (unsigned)(T * T)), dim3(256), ldsb, as_stream(stream), raw, (int)K, T,
+    const size_t ldsb = (size_t)(3 * K * K + 4 * K) * 4;
+    hipLaunchKernelGGL(local_loss_disp_kernel, dim3((unsigned)P, (unsigned)(T * T)), dim3(1024), ldsb, as_stream(stream), raw, (int)K, T,
                        lamda, (float*)ws, grad_raw);
     MISEG_LAUNCH_CHECK("local_loss_disp_kernel");
     hipLaunchKernelGGL(local_loss_finish_kernel, dim3((unsigned)P), dim3(64), 0, as_stream(stream), (const float*)ws, T * T, loss);
@@ -735,7 +754,7 @@ extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t 
     MISEG_REQUIRE(raw && loss && grad_raw, "iic_local_loss_fwd: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && pad >= 0 && P > 0, "iic_local_loss_fwd: bad shape");
     const int T = 2 * (int)pad + 1;
-    const size_t ldsb = (size_t)16 * (2 * K * K + 4 * K) * 4;
+    const size_t ldsb = (size_t)16 * (3 * K * K + 4 * K) * 4;
     MISEG_REQUIRE(ldsb <= (size_t)kLdsBudget, "iic_local_loss_fwd: K too large");
     hipFuncSetAttribute((const void*)local_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipLaunchKernelGGL(local_loss_kernel, dim3((unsigned)P), dim3(1024), ldsb, as_stream(stream), raw, (int)K, T, lamda, loss,
