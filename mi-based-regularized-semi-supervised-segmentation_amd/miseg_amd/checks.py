@@ -15,7 +15,7 @@ from torch import Tensor
 
 from ._cabi import call
 
-_Item = Tuple[Tensor, Callable[[str], BaseException], str]
+_Item = Tuple[object, Callable[[str], BaseException], str]   # (0-d flag tensor | () -> flag tensor, exception type, message)
 _active: Optional[List[_Item]] = None
 
 
@@ -80,5 +80,22 @@ def assert_simplex(t: Tensor, axis: int = 1, msg: str = "") -> None:
 
 
 def raise_if_nan(values: Tensor, describe: str = "nan loss") -> None:
-    """ref iic_loss.py:132-133 / :184-186 raise RuntimeError when a (patch) loss is NaN."""
-    require_zero(torch.isnan(values).sum(), RuntimeError, describe)
+    """ref iic_loss.py:132-133 / :184-186 raise RuntimeError when a (patch) loss is NaN.  Inside a ``deferred`` block the
+    three small kernels of the test (isnan, sum, cast) are not launched here -- in line they sit on the IIC branch's stream
+    between the loss and its backward, i.e. on the step's critical path -- but when the block's flags are gathered
+    (``flag_tensor``), on the stream that makes the iteration's host copy."""
+    if _active is None:
+        require_zero(torch.isnan(values).sum(), RuntimeError, describe)
+        return
+    v = values.detach()
+
+    def count() -> Tensor:
+        if v.is_cuda:
+            v.record_stream(torch.cuda.current_stream(v.device))   # produced on the branch stream, read here
+        return torch.isnan(v).sum().reshape(()).float()
+    _active.append((count, RuntimeError, describe))
+
+
+def flag_tensor(item: _Item) -> Tensor:
+    """The 0-d float flag of a deferred item (evaluates the lazily recorded ones)."""
+    return item[0]() if callable(item[0]) else item[0]

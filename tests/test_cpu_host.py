@@ -279,3 +279,14 @@ def test_deferred_readback_ticket_order_and_flush():
     ticket = pend.post()
     with pytest.raises(AssertionError, match="three bad pixels"):
         _Pending.wait(ticket)
+    # the NaN test of a loss is recorded lazily inside a deferred block (its kernels run when the flags are gathered) and raises
+    # the reference's RuntimeError from wait(); outside a block it raises in line
+    pend = _Pending()
+    with checks.deferred(pend.checks):
+        checks.raise_if_nan(torch.tensor([0.25, float("nan")]), "a patch loss is nan")
+        checks.raise_if_nan(torch.tensor([0.25, 1.0]), "never")
+    assert callable(pend.checks[0][0])
+    with pytest.raises(RuntimeError, match="a patch loss is nan"):
+        _Pending.wait(pend.post())
+    with pytest.raises(RuntimeError, match="inline"):
+        checks.raise_if_nan(torch.tensor(float("nan")), "inline")
