@@ -52,7 +52,13 @@ def windows_tensor(windows, device) -> Tensor:
 
 
 def arange_i32(start: int, stop: int, device) -> Tensor:
-    return cached_const(("arange", str(device), start, stop), lambda: torch.arange(start, stop, dtype=torch.int32, device=device))
+    """Cached int32 [start, stop) on the device; carries its bounds on the host (``_miseg_range``) so that a consumer that
+    scatters into rows ``src`` (local_head's backward) knows which rows it will NOT write without reading the tensor back."""
+    def build():
+        t = torch.arange(start, stop, dtype=torch.int32, device=device)
+        t._miseg_range = (int(start), int(stop))
+        return t
+    return cached_const(("arange", str(device), start, stop), build)
 
 
 def flip_masks(decisions: Sequence[Sequence[bool]]) -> List[int]:
@@ -330,6 +336,7 @@ class _LocalHead(torch.autograd.Function):
              tag=f"head_local_fwd[c{c}]")
         ctx.save_for_backward(feat, w, src, flips, prob)
         ctx.temperature = float(temperature)
+        ctx.src_range = getattr(src, "_miseg_range", None)
         return prob
 
     @staticmethod
@@ -339,7 +346,19 @@ class _LocalHead(torch.autograd.Function):
         s, k, _ = w.shape
         m = src.numel()
         gprob = gprob.contiguous().float()
-        gfeat = zeros_nhwc(bsz, c, h, wd, feat.dtype, feat.device) if ctx.needs_input_grad[0] else None
+        gfeat = None
+        if ctx.needs_input_grad[0]:
+            rng = ctx.src_range
+            if rng is not None and feat.dtype == torch.bfloat16 and k == 20 and s == 5 and c in (16, 32) and 0 <= rng[0] <= rng[1] <= bsz:
+                # the shipped kernels store (not accumulate) every pixel and channel of the rows in src = [start, stop): only the
+                # other rows need the zero fill (a third of the 100 MB at the bench shape, on the step's critical path)
+                gfeat = torch.empty((bsz, c, h, wd), dtype=feat.dtype, device=feat.device, memory_format=torch.channels_last)
+                if rng[0] > 0:
+                    gfeat[:rng[0]].zero_()
+                if rng[1] < bsz:
+                    gfeat[rng[1]:].zero_()
+            else:
+                gfeat = zeros_nhwc(bsz, c, h, wd, feat.dtype, feat.device)
         gw = _stacked_grad(ctx.stack_params[0], w.shape, feat.device)
         gb = _stacked_grad(ctx.stack_params[1], (s, k), feat.device)
         ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)

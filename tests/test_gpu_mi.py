@@ -401,3 +401,27 @@ def test_local_loss_per_displacement_blocks_equal_the_single_block_epilogue(pad,
         outs.append((loss, grad))
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("c", [16, 32])
+def test_local_head_backward_zero_fills_only_rows_outside_a_known_source_range(c):
+    """With src = ops.arange_i32(start, stop) (how the epocher builds it) the backward allocates the tap gradient uninitialised
+    and zero-fills only the rows outside [start, stop): the shipped kernels store every element of the source rows.  Same
+    gradient, bit for bit, as with an anonymous src tensor (full zero fill); rows outside the range exactly zero."""
+    torch.manual_seed(13)
+    bsz, h, w_ = 7, 24, 40
+    feat = torch.randn(bsz, c, h, w_, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt, b = torch.randn(5, 20, c, device=DEV) * 0.3, torch.randn(5, 20, device=DEV)
+    flips = torch.tensor([0, 3, 1, 2], dtype=torch.int32, device=DEV)
+    grads = []
+    for src in (ops().arange_i32(2, 6, DEV), torch.arange(2, 6, dtype=torch.int32, device=DEV)):
+        junk = torch.full((bsz, c, h, w_), float("nan"), device=DEV, dtype=torch.bfloat16)   # poison what the allocator hands out next
+        del junk
+        f = feat.clone().requires_grad_(True)
+        prob = ops().local_head(f, wt, b, src, flips, 1.0)
+        cot = torch.randn(prob.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+        grads.append(torch.autograd.grad((prob * cot).sum(), f)[0])
+    assert hasattr(ops().arange_i32(2, 6, DEV), "_miseg_range")
+    assert torch.equal(grads[0], grads[1])
+    assert float(grads[0][:2].float().abs().max()) == 0.0 and float(grads[0][6:].float().abs().max()) == 0.0
+    assert float(grads[0][2:6].float().abs().max()) > 0.0
