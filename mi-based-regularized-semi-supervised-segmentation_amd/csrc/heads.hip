@@ -1030,6 +1030,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     hipStream_t st = as_stream(stream);
     float* partials = (float*)ws;
     const int nblk = head_w_blocks(M, H * W), R = (int)(S * K), RT = (R + 15) / 16, RP = RT * 16;
+    int nused = nblk;
     size_t lds = ((size_t)RP * 65 + (size_t)64 * (C + 1) + (size_t)RP * (C + 1) + (size_t)4 * std::max<int64_t>(S, 5) * 64) * 4;
     {   // the bf16-MFMA variant's layout: dz planes [2][128][72], features^T [CP][72], W^T planes [2][CP][136] (bf16) + dots
         const size_t cp = (size_t)((C + 15) / 16) * 16;
@@ -1045,7 +1046,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
         // main-stream kernels this side-stream kernel runs next to.  MISEG_HEAD_BWD_BLOCKS overrides (A/B runs).
         static const int cap = [] { const char* e = getenv("MISEG_HEAD_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
         const int nb = cap > 0 ? std::min(cap, nblk) : nblk;
-        if (nb < nblk) hipMemsetAsync(partials + (size_t)nb * (R * C + R), 0, (size_t)(nblk - nb) * (R * C + R) * 4, st);
+        nused = nb;   // the final reduction reads this kernel's nb partials only
         hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nb), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
                            (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials);
     } else
@@ -1066,7 +1067,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
     MISEG_LAUNCH_CHECK("head_local_bwd_fused_kernel");
     const int len = R * (int)C + R;
     float* red = partials + (size_t)nblk * len;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(reduce_grid(len, nblk)), dim3(256), 0, st, partials, nblk, len, red);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(reduce_grid(len, nused)), dim3(256), 0, st, partials, nused, len, red);
     MISEG_LAUNCH_CHECK("sum_partials_kernel");
     launch_split2(st, red, R * (int)C, gw, R, gb);
     return MISEG_OK;
