@@ -42,7 +42,15 @@ def require_zero(bad: Tensor, exc, msg: str) -> None:
         if float(bad) != 0.0:
             raise exc(msg)
     else:
-        _active.append((bad.detach().reshape(()).float(), exc, msg))
+        b = bad.detach()
+        if b.dtype == torch.float32 and b.dim() == 0:
+            _active.append((b, exc, msg))
+        else:   # the cast is one more tiny launch: issued when the flags are gathered, not here (see raise_if_nan)
+            def flag() -> Tensor:
+                if b.is_cuda:
+                    b.record_stream(torch.cuda.current_stream(b.device))
+                return b.reshape(()).float()
+            _active.append((flag, exc, msg))
 
 
 def raise_failed(items: List[_Item], host_flags) -> None:
