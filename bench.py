@@ -202,8 +202,8 @@ def input_pipeline_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lb", type=int, default=16)
     ap.add_argument("--ub", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
