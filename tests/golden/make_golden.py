@@ -165,6 +165,34 @@ def gen_iic():
             out[f"{key}/loss"] = loss
             put_fp(out, f"{key}/gx", gx)
             put_fp(out, f"{key}/gy", gy)
+    # 5. the same three losses on PEAKED, correlated inputs (synth.peaked_pair): MI of O(0.1 .. 1), where "1e-5 relative" can be
+    #    demanded of the loss literally (the near-uniform cases above have losses of 1e-3 .. 1e-6 = differences of O(1) entropies)
+    for npdt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        for (n, k) in ((16, 20), (64, 5)):
+            key = f"gpeak_{tag}_n{n}_k{k}"
+            xs, ys = synth.peaked_pair(key, (n, k), npdt)
+            x, y = T(xs).requires_grad_(True), T(ys).requires_grad_(True)
+            loss, loss_nl, p = IIDLoss()(x, y)
+            gx, gy = torch.autograd.grad(loss, [x, y])
+            out.update({f"{key}/loss": loss, f"{key}/loss_no_lamb": loss_nl, f"{key}/joint": p, f"{key}/gx": gx, f"{key}/gy": gy})
+        for (n, k, h, w, p) in ((3, 5, 12, 10, 2), (4, 20, 32, 32, 1), (4, 20, 32, 32, 3), (2, 8, 64, 64, 3)):
+            key = f"lpeak_{tag}_n{n}_k{k}_h{h}_w{w}_p{p}"
+            xs, ys = synth.peaked_pair(key, (n, k, h, w), npdt)
+            x, y = T(xs).requires_grad_(True), T(ys).requires_grad_(True)
+            loss = IIDSegmentationLoss(padding=p)(x, y)
+            gx, gy = torch.autograd.grad(loss, [x, y])
+            out[f"{key}/loss"] = loss
+            put_fp(out, f"{key}/gx", gx)
+            put_fp(out, f"{key}/gy", gy)
+        for (n, k, h, w, p, patch) in ((2, 4, 100, 100, 1, 32), (1, 20, 96, 96, 3, 32)):
+            key = f"ppeak_{tag}_n{n}_k{k}_h{h}_w{w}_p{p}_ps{patch}"
+            xs, ys = synth.peaked_pair(key, (n, k, h, w), npdt)
+            x, y = T(xs).requires_grad_(True), T(ys).requires_grad_(True)
+            loss = IIDSegmentationSmallPathLoss(padding=p, patch_size=patch)(x, y, None)
+            gx, gy = torch.autograd.grad(loss, [x, y])
+            out[f"{key}/loss"] = loss
+            put_fp(out, f"{key}/gx", gx)
+            put_fp(out, f"{key}/gy", gy)
     # 4. patch_generator geometry
     for (h, patch) in ((100, 32), (64, 1024), (512, 128), (224, 1024), (48, 16), (33, 16)):
         fm = torch.arange(h * h, dtype=torch.float32).view(1, 1, h, h)
@@ -438,15 +466,14 @@ def gen_step():
 
 
 def main():
+    """``python make_golden.py [iic heads unet losses meters_sched step ...]`` -- no arguments = every fixture."""
     scratch = import_reference()
+    gens = {"iic": gen_iic, "heads": gen_heads, "unet": gen_unet, "losses": gen_losses, "meters_sched": gen_meters_sched,
+            "step": gen_step}
     try:
         torch.set_num_threads(8)
-        gen_iic()
-        gen_heads()
-        gen_unet()
-        gen_losses()
-        gen_meters_sched()
-        gen_step()
+        for name in (sys.argv[1:] or list(gens)):
+            gens[name]()
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 

@@ -38,6 +38,32 @@ def probs(tag: str, shape, dtype=np.float32, temperature: float = 1.0) -> np.nda
     return (e / e.sum(axis=1, keepdims=True)).astype(dtype)
 
 
+def _softmax1(z: np.ndarray) -> np.ndarray:
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def peaked_pair(tag: str, shape, dtype=np.float32, sharpness: float = 6.0, agree: float = 0.9, block: int = 4):
+    """Two CORRELATED, PEAKED per-pixel simplexes (x, y) along axis 1: a trained head's regime, where the mutual information is
+    O(0.1 .. 1) instead of the O(1e-3 .. 1e-6) of ``probs`` (independent near-uniform fields).  A shared class field -- piecewise
+    constant over ``block`` x ``block`` pixels for 4-D shapes, so neighbouring displacements carry information too -- drives both;
+    ``agree`` mixes it with independent noise.  float64 math, one rounding."""
+    rs = np.random.RandomState(_seed(tag))
+    shape = tuple(shape)
+    if len(shape) == 4:
+        n, k, h, w = shape
+        low = rs.standard_normal((n, k, -(-h // block), -(-w // block)))
+        shared = np.repeat(np.repeat(low, block, axis=2), block, axis=3)[:, :, :h, :w]
+    else:
+        shared = rs.standard_normal(shape)
+    nx, ny = rs.standard_normal(shape), rs.standard_normal(shape)
+    mix = np.sqrt(max(0.0, 1.0 - agree * agree))
+    x = _softmax1(sharpness * (agree * shared + mix * nx))
+    y = _softmax1(sharpness * (agree * shared + mix * ny))
+    return x.astype(dtype), y.astype(dtype)
+
+
 def mask(tag: str, shape, keep: float = 0.7) -> np.ndarray:
     return (np.random.RandomState(_seed(tag)).random_sample(tuple(shape)) < keep).astype(np.float32)
 

@@ -80,13 +80,24 @@ def test_epocher_matches_reference_run(golden, mode):
         for k in ("mi/mean", "individual_mis/Conv5", "individual_mis/Up_conv3", "individual_mis/Up_conv2"):
             np.testing.assert_allclose(got[k], ref[k], rtol=0.2, atol=5e-6)
         assert got["iic_weight/mean"] == ref["iic_weight/mean"] and got["uda_weight/mean"] == ref["uda_weight/mean"]
-    # weights after two Adam steps: every entry moved by at most ~lr per step; sign-noise gradients bound the deviation
+    # Weights after two Adam steps.  Adam moves every weight by ~lr per step whatever the gradient size, so comparing the weights
+    # themselves says nothing about the gradients (a wrong-sign gradient would still land within 2*lr): the gradients are compared
+    # directly in test_step_gradients_match_reference.  What IS checked here is the update DIRECTION: wherever the reference moved a
+    # weight by more than 1.2*lr over the two steps (both steps agreed in sign), this run must have moved it the same way.
+    init = OU.init_state(1, 4, seed=9)
+    agree, total = 0, 0
     for k, v in model.state_dict().items():
+        if not k.endswith(("weight", "bias")):
+            continue
         fp = synth.fp_unpack(g, f"{mode}/model_after/{k}")
-        synth.check_fingerprint(v.detach().float().cpu().numpy(), fp, f"{mode}/model_after/{k}", rtol=2e-3,
-                                atol=2.5 * STEP["lr"] * STEP["NB"])
-    moved = float((model.state_dict()["Conv1.conv.0.weight"].cpu() - OU.init_state(1, 4, seed=9)["Conv1.conv.0.weight"]).abs().mean())
-    assert 0.2 * STEP["lr"] < moved < 2.5 * STEP["lr"] * STEP["NB"], moved   # the optimiser really stepped
+        idx = synth.sample_index(v.numel(), f"{mode}/model_after/{k}")
+        mine = v.detach().float().cpu().numpy().reshape(-1).astype(np.float64)[idx] - init[k].numpy().reshape(-1).astype(np.float64)[idx]
+        ref_move = fp["sample"] - init[k].numpy().reshape(-1).astype(np.float64)[idx]
+        sel = np.abs(ref_move) > 1.2 * STEP["lr"]
+        agree += int((np.sign(mine[sel]) == np.sign(ref_move[sel])).sum())
+        total += int(sel.sum())
+        assert np.abs(mine).max() <= 2.5 * STEP["lr"] * STEP["NB"], k
+    assert total > 1000 and agree >= 0.97 * total, (agree, total)
 
 
 def test_udaiic_step_bf16_runs_and_tracks_fp32(golden):
@@ -141,6 +152,107 @@ def test_first_iteration_is_tight(golden, mode):
         np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
         for f in FEATURES:
             np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
+
+
+def _first_iteration_gradients(mode, dtype, monkeypatch, wgrad_side=True, iic_side=True):
+    """Run iteration 1 of the epocher and return {reference parameter name: gradient} as the optimiser kernel sees them: the flat
+    gradient buffer is cloned between FlatBuffers.collect() and miseg_adam_step (the only place all slots are final)."""
+    from miseg_amd import unet_ops
+    from semi_seg.epocher import TrainEpocher, UDAIICEpocher
+    monkeypatch.setattr(unet_ops, "_WGRAD_SIDE", wgrad_side)
+    monkeypatch.setenv("MISEG_IIC_STREAM", "1" if iic_side else "0")
+    model, pw, lw, opt, lab, unl, kl = build(mode, dtype)
+    grabbed = []
+    real = unet_ops.adam_step
+
+    def spy(param, grad, *a, **k):
+        grabbed.append(grad.detach().clone())
+        return real(param, grad, *a, **k)
+
+    monkeypatch.setattr(unet_ops, "adam_step", spy)
+    random.seed(1234)
+    if mode == "udaiic":
+        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0, device=DEV,
+                           feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=STEP["cons_weight"],
+                           iic_weight=STEP["iic_weight"])
+    else:
+        ep = TrainEpocher(model, opt, lab, unl, kl, 0, 1, 0, DEV, feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25])
+    ep.run()
+    assert len(grabbed) == 1
+    flat, fb = grabbed[0].cpu(), opt.flat
+    named = list(model.named_parameters()) + ([("proj/" + n, p) for n, p in pw.named_parameters()] if mode == "udaiic" else [])
+    out = {}
+    for name, p in named:
+        o = fb.offset_of(p)
+        out[name] = flat[o:o + p.numel()].view(p.shape).numpy()
+    return out
+
+
+def _gradient_errors(g, mode, grads):
+    """Per parameter: relative L2 error over the fingerprint sample, and max |error| relative to the tensor's largest entry."""
+    names = [str(n) for n in g[f"{mode}/param_names"]]
+    assert sorted(names) == sorted(grads), set(names) ^ set(grads)
+    rows = {}
+    for n in names:
+        fp = synth.fp_unpack(g, f"{mode}/grad_step1/{n}")
+        got = grads[n].reshape(-1).astype(np.float64)[synth.sample_index(grads[n].size, f"{mode}/grad_step1/{n}")]
+        ref = fp["sample"]
+        rows[n] = (float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)), float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)),
+                   float(np.abs(ref).max()))
+    return rows
+
+
+def _dump(tag, rows):
+    """Achieved errors go to gpurun_out/ (merged back from the GPU box) so DESIGN.md can quote them."""
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"step_grad_errors_{tag}.json"), "w") as f:
+        json.dump({k: {"rel_l2": v[0], "max_rel_to_scale": v[1], "scale": v[2]} for k, v in rows.items()}, f, indent=1)
+
+
+@pytest.mark.parametrize("wgrad_side,iic_side", [(True, True), (False, False)])
+@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+def test_step_gradients_match_reference(golden, monkeypatch, mode, wgrad_side, iic_side):
+    """Every parameter gradient of iteration 1 -- through the flat-gradient slots, the wgrad side stream, the IIC side stream, the
+    symbolic loss seeding and the partial zero-fill of the tap gradient -- against the gradients the REFERENCE's own epocher handed
+    to its optimiser (step.npz `{mode}/grad_step1/*`, recorded by tests/golden/make_golden.py::RecordingAdam), with the side
+    streams on (shipped) and off.  fp32 mode.  Bounds: the last decoder block, the logits layer and the decoder-tap heads see at
+    most two ReLUs / no BatchNorm statistics downstream and must be tight; deeper layers inherit ReLU-mask flips (see
+    test_unet_fp32_vs_golden) and are bounded in relative L2."""
+    g = golden("step")
+    grads = _first_iteration_gradients(mode, "float32", monkeypatch, wgrad_side, iic_side)
+    rows = _gradient_errors(g, mode, grads)
+    _dump(f"{mode}_fp32_w{int(wgrad_side)}i{int(iic_side)}", rows)
+    worst = {k: v[0] for k, v in rows.items()}
+    bad = {k: v for k, v in worst.items() if v > 5e-2 and rows[k][2] > 1e-7}     # 1e-7: the global-MI heads' gradients are fp32 noise
+    assert not bad, bad
+    tail = sorted(v for k, v in worst.items() if k.startswith(("Up_conv2", "DeConv")))
+    assert tail[len(tail) // 2] < 2e-3 and tail[0] < 2e-4, tail
+    if mode == "udaiic":
+        dec_heads = sorted(v for k, v in worst.items() if "_decoder_projectors" in k)
+        assert dec_heads[-1] < 2e-2 and dec_heads[len(dec_heads) // 2] < 5e-3, dec_heads
+    # a wrong sign, a missing term or a stale slot shows up as rel_l2 ~ 1 or 2: nothing may be anywhere near that
+    assert max(v for k, v in worst.items() if rows[k][2] > 1e-7) < 0.1
+
+
+def test_step_gradients_bf16_track_reference(golden, monkeypatch):
+    """The same comparison in the bench's arithmetic (bf16 activations, bf16x3 local MI): bf16 rounding of 23 layers of a
+    random-init net bounds what is reachable (the forward logits differ by ~17 % RMS, test_unet_256_fp32_and_bf16), so this guards
+    orchestration (sign / missing term / stale slot => rel_l2 >= 1) and records the achieved errors."""
+    from miseg_amd import ops as _ops
+    g = golden("step")
+    _ops.set_mi_precision("bf16x3")
+    try:
+        grads = _first_iteration_gradients("udaiic", "bfloat16", monkeypatch)
+    finally:
+        _ops.set_mi_precision("fp32")
+    rows = _gradient_errors(g, "udaiic", grads)
+    _dump("udaiic_bf16", rows)
+    sig = {k: v[0] for k, v in rows.items() if v[2] > 1e-7}
+    assert max(sig.values()) < 0.6, {k: v for k, v in sig.items() if v >= 0.6}
+    vals = sorted(sig.values())
+    assert vals[len(vals) // 2] < 0.15, vals[len(vals) // 2]
 
 
 def test_deferred_readback_records_every_iteration_like_the_synchronous_one():

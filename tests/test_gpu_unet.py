@@ -38,7 +38,6 @@ def ref_layer(x, w, bn, training, pool):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", ["plain_pool", "concat", "upsample", "eval", "odd_size"])
 def test_conv_bn_relu_layer(dtype, case):
-    from miseg_amd import unet_ops
     n, h, w = 3, 24, 40
     c0, c1, cout, ups0, pool, training = 16, 0, 32, 0, False, True
     if case == "plain_pool":
@@ -51,6 +50,39 @@ def test_conv_bn_relu_layer(dtype, case):
         training = False
     elif case == "odd_size":
         h, w, c0, cout = 20, 36, 8, 32
+    _layer_case(dtype, case, n, h, w, c0, c1, cout, ups0, pool, training)
+
+
+# (n, h, w, c0, c1, cout, ups0, pool): every shape has >= 512 16x32 tiles and <= 32 input channels, i.e. goes to
+# conv3x3_stream_kernel<COT, 32, NV, DU> (csrc/conv.hip conv_streams()), forward AND both dgrads; the six instantiations the
+# 256^2 / 128^2 layers of the bench use are all here (16->16, 16->32, 32->32, upsampled 32->16, concat 16+16->16, stem 8->16)
+STREAM_CASES = {
+    "s16_16_pool": (4, 256, 256, 16, 0, 16, 0, True),
+    "s16_32": (16, 128, 128, 16, 0, 32, 0, False),
+    "s32_32_pool": (16, 128, 128, 32, 0, 32, 0, True),
+    "s_up32_16": (4, 256, 256, 32, 0, 16, 1, False),
+    "s_cat16_16_16": (4, 256, 256, 16, 16, 16, 0, False),
+    "s_stem8_16": (4, 256, 256, 8, 0, 16, 0, False),
+    "s_cat8_16_16": (6, 250, 230, 8, 16, 16, 0, False),      # ragged: H % 16 != 0, W % 32 != 0, 24 input channels
+    "s24_32": (6, 250, 230, 24, 0, 32, 0, False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(STREAM_CASES))
+def test_conv_bn_relu_layer_streaming_bf16(case):
+    """The persistent streaming conv (the kernel the bench's 256^2 / 128^2 layers run) against the oracle on the same bf16-rounded
+    operands, same bounds as the generic kernel above: output within one bf16 ulp, gradients as test_conv_bn_relu_layer."""
+    from miseg_amd import _cabi
+    n, h, w, c0, c1, cout, ups0, pool = STREAM_CASES[case]
+    assert c0 + c1 <= 32 and n * ((h + 15) // 16) * ((w + 31) // 32) >= 512     # conv_streams() of csrc/conv.hip
+    # the streaming kernel hands BatchNorm one partial per persistent block (<= 512), the generic one a partial per tile
+    tiles = n * ((h + 15) // 16) * ((w + 31) // 32)
+    assert _cabi.query("miseg_conv3x3_stats_parts", _cabi.BF16, c0 + c1, n, h, w) == min(tiles, 512)
+    _layer_case(torch.bfloat16, case, n, h, w, c0, c1, cout, ups0, pool, True)
+
+
+def _layer_case(dtype, case, n, h, w, c0, c1, cout, ups0, pool, training):
+    from miseg_amd import unet_ops
     rnd = (lambda t: t.to(dtype).float()) if dtype == torch.bfloat16 else (lambda t: t)
     x0 = rnd(T(synth.normal(f"layer/{case}/x0", (n, c0, h >> ups0, w >> ups0))))
     x1 = rnd(T(synth.normal(f"layer/{case}/x1", (n, c1, h, w)))) if c1 else None

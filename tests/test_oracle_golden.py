@@ -96,6 +96,54 @@ def test_patch_local_mi(golden, tag, n, k, h, w, p, patch, use_mask):
         synth.check_fingerprint(val.numpy(), synth.fp_unpack(g, f"{key}/{nm}"), f"{key}/{nm}", rtol=rt, atol=gscale * rt)
 
 
+PEAK_GLOBAL = [(16, 20), (64, 5)]
+PEAK_LOCAL = [(3, 5, 12, 10, 2), (4, 20, 32, 32, 1), (4, 20, 32, 32, 3), (2, 8, 64, 64, 3)]
+PEAK_PATCH = [(2, 4, 100, 100, 1, 32), (1, 20, 96, 96, 3, 32)]
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_peaked_inputs_literal_relative_tolerance(golden, tag):
+    """Correlated, peaked inputs (synth.peaked_pair): the losses are O(0.1 .. 1), so north_star's '1e-5 relative' is held literally
+    (fp64: 1e-10) for all three losses; gradients at 1e-4 of their scale (fp64: 1e-8)."""
+    g = golden("iic")
+    dt = np.float32 if tag == "f32" else np.float64
+    lrt, grt = (1e-5, 1e-4) if tag == "f32" else (1e-10, 1e-8)
+    for n, k in PEAK_GLOBAL:
+        key = f"gpeak_{tag}_n{n}_k{k}"
+        xs, ys = synth.peaked_pair(key, (n, k), dt)
+        x, y = T(xs).requires_grad_(True), T(ys).requires_grad_(True)
+        loss, loss_nl, p = OI.iid_loss(x, y)
+        assert abs(float(g[f"{key}/loss"])) > 0.1
+        np.testing.assert_allclose(float(loss), float(g[f"{key}/loss"]), rtol=lrt)
+        np.testing.assert_allclose(float(loss_nl), float(g[f"{key}/loss_no_lamb"]), rtol=lrt)
+        np.testing.assert_allclose(p.detach().numpy(), g[f"{key}/joint"], rtol=lrt, atol=lrt * 1e-3)
+        gx, gy = torch.autograd.grad(loss, [x, y])
+        sc = float(np.abs(g[f"{key}/gx"]).max())
+        np.testing.assert_allclose(gx.numpy(), g[f"{key}/gx"], rtol=grt, atol=grt * sc)
+        np.testing.assert_allclose(gy.numpy(), g[f"{key}/gy"], rtol=grt, atol=grt * sc)
+    for n, k, h, w, p_ in PEAK_LOCAL:
+        key = f"lpeak_{tag}_n{n}_k{k}_h{h}_w{w}_p{p_}"
+        xs, ys = synth.peaked_pair(key, (n, k, h, w), dt)
+        x, y = T(xs).requires_grad_(True), T(ys).requires_grad_(True)
+        loss = OI.iid_seg_loss(x, y, p_)
+        assert abs(float(g[f"{key}/loss"])) > 0.1
+        np.testing.assert_allclose(float(loss), float(g[f"{key}/loss"]), rtol=lrt)
+        gx, gy = torch.autograd.grad(loss, [x, y])
+        sc = float(np.abs(synth.fp_unpack(g, f"{key}/gx")["sample"]).max())
+        for nm, val in (("gx", gx), ("gy", gy)):
+            synth.check_fingerprint(val.numpy(), synth.fp_unpack(g, f"{key}/{nm}"), f"{key}/{nm}", rtol=grt, atol=sc * grt)
+    for n, k, h, w, p_, patch in PEAK_PATCH:
+        key = f"ppeak_{tag}_n{n}_k{k}_h{h}_w{w}_p{p_}_ps{patch}"
+        xs, ys = synth.peaked_pair(key, (n, k, h, w), dt)
+        x, y = T(xs).requires_grad_(True), T(ys).requires_grad_(True)
+        loss = OI.iid_seg_small_patch_loss(x, y, p_, patch)
+        np.testing.assert_allclose(float(loss), float(g[f"{key}/loss"]), rtol=lrt)
+        gx, gy = torch.autograd.grad(loss, [x, y])
+        sc = float(np.abs(synth.fp_unpack(g, f"{key}/gx")["sample"]).max())
+        for nm, val in (("gx", gx), ("gy", gy)):
+            synth.check_fingerprint(val.numpy(), synth.fp_unpack(g, f"{key}/{nm}"), f"{key}/{nm}", rtol=grt, atol=sc * grt)
+
+
 @pytest.mark.parametrize("h,patch", [(100, 32), (64, 1024), (512, 128), (224, 1024), (48, 16), (33, 16)])
 def test_patch_geometry(golden, h, patch):
     wins = OI.patch_windows(h, h, (patch, patch), (patch // 2, patch // 2))
