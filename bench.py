@@ -2,7 +2,9 @@
 """Benchmark of the udaiic train step (BASELINE.json metric: images/sec, UNet+IIC fwd/bwd, ACDC 256^2).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 either way: under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`` this
+     process IS one of the N ranks; started plainly, it spawns the N ranks itself -- one child process per GPU, before anything
+     here touches the GPU, never an exec -- relays rank 0's JSON line and exits non-zero if any rank failed)
 
 A "step" is one full optimisation step of ``UDAIICEpocher`` (one U-Net forward on LB+2*UB slices, supervised KL,
 UDA MSE, global+local IIC on three taps x five sub-heads, one backward, fused Adam) on synthetic ACDC-shaped
@@ -199,6 +201,48 @@ def input_pipeline_bench(args):
         torch.distributed.destroy_process_group()
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """Plain ``python bench.py --gpus N``: start N child processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1), relay rank 0's stdout, wait.  The parent never initialises the GPU and never execs; a failing rank
+    ends the others (they would otherwise wait in a collective) and becomes the exit code."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    pump.join(timeout=5)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,7 +266,11 @@ def main():
     ap.add_argument("--workload", default="step", choices=["step", "input"],
                     help="step = the udaiic train step (BASELINE metric, default); input = the device-resident input pipeline "
                          "alone (SURVEY.md 8(f-2)): one labeled + one unlabeled batch, two augmented views each")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks as child processes even for --gpus 1 (the N > 1 default when "
+                                                         "not launched by torch.distributed.run)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(spawn_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--spawn"]))
     if args.workload == "input":
         return input_pipeline_bench(args)
     if args.data == "acdc":
@@ -231,7 +279,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -312,6 +360,9 @@ def main():
                                    f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
                        "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
                        "parallelism": f"dp{world}", "step_graph": bool(use_graph)},
+            # what the collective library actually saw (1 / null when this is a single process without torch.distributed)
+            "rccl_ranks": torch.distributed.get_world_size() if distributed else 1,
+            "backend": torch.distributed.get_backend() if distributed else None,
         }
         if table:
             if timer is not None and timer.records:

@@ -15,6 +15,25 @@ from deepclustering2.writer import SummaryWriter
 _BUFFER_NAMES = ("_best_score", "_start_epoch", "_cur_epoch")
 
 
+def _rank() -> int:
+    """Rank in the data-parallel job (0 without torch.distributed)."""
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class _NullWriter:
+    """What the non-writing ranks of a data-parallel job log to."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
 class Trainer(metaclass=ABCMeta):
     RUN_PATH = str(Path.cwd() / "runs")
 
@@ -24,20 +43,29 @@ class Trainer(metaclass=ABCMeta):
         if not Path(save_dir).is_absolute():
             save_dir = str(Path(self.RUN_PATH) / save_dir)
         self._save_dir = save_dir
-        Path(self._save_dir).mkdir(exist_ok=True, parents=True)
+        if self.is_writer:
+            Path(self._save_dir).mkdir(exist_ok=True, parents=True)
         self._best_score, self._start_epoch, self._cur_epoch = -1, 0, 0
         self._max_epoch, self._num_batches = max_epoch, num_batches
         self._config = deepcopy(configuration)
-        if self._config:
+        if self._config and self.is_writer:
             write_yaml(self._config, save_dir, save_name="config.yaml")
         self._storage = Storage()
         self._model = model
         self._device = torch.device(device)
 
+    @property
+    def is_writer(self) -> bool:
+        """One process per GPU: only rank 0 touches the run directory (config.yaml, checkpoints, csv, TensorBoard)."""
+        return _rank() == 0
+
     # ---- loop scaffolding
+    def _writer_context(self):
+        return SummaryWriter(str(self._save_dir)) if self.is_writer else _NullWriter()
+
     def start_training(self, *args, **kwargs):
         self.to(self._device)
-        with SummaryWriter(str(self._save_dir)) as self._writer:
+        with self._writer_context() as self._writer:
             return self._start_training(*args, **kwargs)
 
     @abstractmethod
@@ -121,6 +149,9 @@ class Trainer(metaclass=ABCMeta):
         self.load_state_dict_from_path(checkpoint, **kwargs)
 
     def save(self, current_score: float, path=None):
+        if not self.is_writer:
+            self._best_score = max(self._best_score, current_score)
+            return
         self._save_to("last.pth", path)
         if self._best_score < current_score:
             self._best_score = current_score

@@ -33,6 +33,7 @@ def init_from_env(backend: Optional[str] = None) -> bool:
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     if not dist.is_initialized():
+        backend = os.environ.get("MISEG_DDP_BACKEND") or backend     # e.g. gloo: several ranks on ONE GPU (tests), or CPU tensors
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

@@ -1,185 +1,199 @@
-"""Feature taps, projector heads and per-feature IIC criteria (ref: semi_seg/_utils.py:12-224).
+"""Feature taps, projector-head banks and per-tap IIC criteria of the semi-supervised trainers.
 
-Same classes / constructor arguments / iteration order as the reference so ``semi_seg.trainer`` wires them
-identically: encoder taps first (global ``IIDLoss``), then decoder taps (``IIDSegmentationSmallPathLoss``
-with per-feature padding / patch size).
+Public surface of ref ``semi_seg/_utils.py:12-224`` -- ``FeatureExtractor``, ``ProjectorWrapper`` (``init_encoder`` /
+``init_decoder``), ``IICLossWrapper``, the two cluster-wrapper classes and ``IIDLoss`` -- with the reference's
+constructor arguments, iteration order (encoder taps first, then decoder taps: the epocher zips taps, heads and criteria
+positionally, ref ``semi_seg/epocher.py:244-246``) and checkpoint keys (``_encoder_projectors._clusters.<tap>...``,
+``_decoder_projectors._clusters.<tap>...``).  Everything behind that surface is this repo's own: one ``_HeadBank``
+builds either kind of head from a factory, per-tap options are broadcast by ``_per_tap``, and the extractor is a plain
+name -> latest-output table whose hooks can also notify a listener the moment a tap exists (the IIC branch starts on its
+own HIP stream from that callback, ``semi_seg/epocher.py::IICTrainEpocher._on_feature``).
 """
 from __future__ import annotations
 
-from itertools import repeat
-from typing import Iterable, List, Union
+from typing import Callable, Dict, Iterator, List, Optional, Sequence, Union
 
 from torch import Tensor, nn
 
 from contrastyou.arch import UNet
-from contrastyou.losses.iic_loss import IIDLoss as _IIDLoss, IIDSegmentationSmallPathLoss
-from contrastyou.trainer._utils import ClusterHead as _EncoderClusterHead, LocalClusterHead as _LocalClusterHead
+from contrastyou.losses.iic_loss import IIDLoss as _GlobalIID, IIDSegmentationSmallPathLoss
+from contrastyou.trainer._utils import ClusterHead, LocalClusterHead
 
-_ENCODER = ["Conv1", "Conv2", "Conv3", "Conv4", "Conv5"]
-_DECODER = ["Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3", "Up2", "Up_conv2", "DeConv_1x1"]
+# which side of the U-Net a tap sits on decides the head kind (pooled vs per-pixel) and the criterion (global vs local MI)
+_SIDE: Dict[str, str] = {**{f"Conv{i}": "encoder" for i in range(1, 6)},
+                         **{n: "decoder" for n in ("Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3", "Up2", "Up_conv2",
+                                                   "DeConv_1x1")}}
 
 
-class IIDLoss(_IIDLoss):
-    """Returns only the loss term (ref _utils.py:12-15)."""
+def _names(feature_names: Union[str, Sequence[str]]) -> List[str]:
+    return [feature_names] if isinstance(feature_names, str) else list(feature_names)
+
+
+def _on_side(feature_names, side: str) -> List[str]:
+    return [f for f in _names(feature_names) if _SIDE.get(f) == side]
+
+
+def _per_tap(value, count: int, what: str) -> list:
+    """A scalar option applies to every tap; a list must give one entry per tap."""
+    if isinstance(value, (list, tuple)):
+        if len(value) != count:
+            raise AssertionError(f"{what}: {len(value)} values for {count} feature(s)")
+        return list(value)
+    return [value] * count
+
+
+class IIDLoss(_GlobalIID):
+    """The global criterion as the wrapper hands it out: the loss term only (ref _utils.py:12-15)."""
 
     def forward(self, x_out: Tensor, x_tf_out: Tensor):
-        return super().forward(x_out, x_tf_out)[0]
-
-
-def _filter_encodernames(feature_list):
-    return [f for f in feature_list if f in _ENCODER]
-
-
-def _filter_decodernames(feature_list):
-    return [f for f in feature_list if f in _DECODER]
-
-
-def _nlist(n):
-    def parse(x):
-        if isinstance(x, Iterable) and not isinstance(x, str):
-            assert len(x) == n, (len(x), n)
-            return list(x)
-        return list(repeat(x, n))
-    return parse
+        loss, _without_lambda, _joint = super().forward(x_out, x_tf_out)
+        return loss
 
 
 class FeatureExtractor(nn.Module):
-    """Context manager that taps named sub-modules with forward hooks (ref _utils.py:38-78)."""
-
-    class _Tap:
-        feature = None
-
-        def __init__(self, owner=None, name=None):
-            self._owner, self._name = owner, name
-
-        def __call__(self, _module, _inputs, result):
-            self.feature = result
-            cb = getattr(self._owner, "on_feature", None)   # optional: consumers that want the tap the moment it exists
-            if cb is not None:
-                cb(self._name, result)
+    """``with FeatureExtractor(net, names) as fx: net(x); fx["Up_conv2"]`` -- latest output of each named sub-module,
+    kept in ``names`` order (ref _utils.py:38-78).  ``fx.on_feature = fn`` makes every hook call ``fn(name, output)`` as
+    soon as the module has produced it."""
 
     def __init__(self, net: UNet, feature_names: Union[List[str], str]) -> None:
         super().__init__()
         self._net = net
-        self._feature_names = [feature_names] if isinstance(feature_names, str) else feature_names
-        self.on_feature = None
-        for f in self._feature_names:
-            assert f in _ENCODER + _DECODER, f
+        self._feature_names = _names(feature_names)
+        unknown = [f for f in self._feature_names if f not in _SIDE]
+        assert not unknown, f"unknown feature name(s) {unknown}"
+        self.on_feature: Optional[Callable[[str, Tensor], None]] = None
+        self._latest: Dict[str, Optional[Tensor]] = {}
+        self._handles: list = []
 
-    def __enter__(self):
-        self._feature_exactors, self._hook_handlers = {}, {}
-        for f in self._feature_names:
-            tap = self._Tap(self, f)
-            self._hook_handlers[f] = getattr(self._net, f).register_forward_hook(tap)
-            self._feature_exactors[f] = tap
+    def _hook_for(self, name: str):
+        def hook(_module, _inputs, output):
+            self._latest[name] = output
+            listener = self.on_feature
+            if listener is not None:
+                listener(name, output)
+        return hook
+
+    def __enter__(self) -> "FeatureExtractor":
+        self._latest = {name: None for name in self._feature_names}
+        self._handles = [getattr(self._net, name).register_forward_hook(self._hook_for(name)) for name in self._feature_names]
         return self
 
-    def __exit__(self, exc_type, exc_val, exc_tb):
-        for handle in self._hook_handlers.values():
-            handle.remove()
-        del self._feature_exactors, self._hook_handlers
+    def __exit__(self, *exc) -> None:
+        while self._handles:
+            self._handles.pop().remove()
+        self._latest = {}
 
-    def __getitem__(self, item):
-        return self._feature_exactors[item].feature
+    def __getitem__(self, name: str) -> Tensor:
+        return self._latest[name]
 
-    def get_feature_from_num(self, num):
-        return self[self._feature_names[num]]
+    def get_feature_from_num(self, num: int) -> Tensor:
+        return self._latest[self._feature_names[num]]
 
-    def __iter__(self):
-        for tap in self._feature_exactors.values():
-            yield tap.feature
+    def __iter__(self) -> Iterator[Tensor]:
+        return iter([self._latest[name] for name in self._feature_names])
 
 
-class LocalClusterWrappaer(nn.Module):
-    """One (Local)ClusterHead per feature name (ref _utils.py:81-134)."""
+class _HeadBank(nn.Module):
+    """``_clusters[tap]`` = one multi-sub-head projector per tap; options broadcast per tap."""
+
+    head_factory: Callable[..., nn.Module] = None
 
     def __init__(self, feature_names, head_types="linear", num_subheads=5, num_clusters=10, normalize=False) -> None:
         super().__init__()
-        self._feature_names = [feature_names] if isinstance(feature_names, str) else feature_names
-        n = _nlist(len(self._feature_names))
-        self._clusters = nn.ModuleDict()
-        for f, h, c, s, nm in zip(self._feature_names, n(head_types), n(num_clusters), n(num_subheads), n(normalize)):
-            self._clusters[f] = self._create_clusterheads(input_dim=UNet.dimension_dict[f], head_type=h, num_clusters=c,
-                                                          num_subheads=s, normalize=nm)
+        self._feature_names = _names(feature_names)
+        n = len(self._feature_names)
+        options = zip(self._feature_names, _per_tap(head_types, n, "head_types"), _per_tap(num_clusters, n, "num_clusters"),
+                      _per_tap(num_subheads, n, "num_subheads"), _per_tap(normalize, n, "normalize"))
+        self._clusters = nn.ModuleDict({
+            tap: type(self).head_factory(input_dim=UNet.dimension_dict[tap], head_type=kind, num_clusters=clusters,
+                                         num_subheads=subheads, normalize=norm)
+            for tap, kind, clusters, subheads, norm in options})
 
-    def __len__(self):
-        return len(self._feature_names)
+    def __len__(self) -> int:
+        return len(self._clusters)
 
     def __iter__(self):
-        yield from self._clusters.values()
+        return iter(self._clusters.values())
 
-    def __getitem__(self, item):
-        return self._clusters[item]
+    def __getitem__(self, tap: str) -> nn.Module:
+        return self._clusters[tap]
 
-    @staticmethod
-    def _create_clusterheads(*args, **kwargs):
-        return _LocalClusterHead(*args, **kwargs)
+    def __contains__(self, tap: str) -> bool:
+        return tap in self._clusters
 
 
-class EncoderClusterWrapper(LocalClusterWrappaer):
-    @staticmethod
-    def _create_clusterheads(*args, **kwargs):
-        return _EncoderClusterHead(*args, **kwargs)
+class LocalClusterWrappaer(_HeadBank):      # (sic) the reference's public name, ref _utils.py:81
+    head_factory = LocalClusterHead
+
+
+class EncoderClusterWrapper(_HeadBank):
+    head_factory = ClusterHead
 
 
 class ProjectorWrapper(nn.Module):
+    """Encoder bank + decoder bank; iterating yields the heads in tap order, encoder side first."""
+
     ENCODER_INITIALIZED = False
     DECODER_INITIALIZED = False
 
     def init_encoder(self, feature_names, head_types="linear", num_subheads=5, num_clusters=10, normalize=False):
-        self._encoder_names = _filter_encodernames(feature_names)
+        self._encoder_names = _on_side(feature_names, "encoder")
         self._encoder_projectors = EncoderClusterWrapper(self._encoder_names, head_types, num_subheads, num_clusters, normalize)
         self.ENCODER_INITIALIZED = True
 
     def init_decoder(self, feature_names, head_types="linear", num_subheads=5, num_clusters=10, normalize=False):
-        self._decoder_names = _filter_decodernames(feature_names)
+        self._decoder_names = _on_side(feature_names, "decoder")
         self._decoder_projectors = LocalClusterWrappaer(self._decoder_names, head_types, num_subheads, num_clusters, normalize)
         self.DECODER_INITIALIZED = True
 
+    def _banks(self) -> List[_HeadBank]:
+        return [getattr(self, attr) for flag, attr in ((self.ENCODER_INITIALIZED, "_encoder_projectors"),
+                                                       (self.DECODER_INITIALIZED, "_decoder_projectors")) if flag]
+
     @property
-    def feature_names(self):
+    def feature_names(self) -> List[str]:
         return self._encoder_names + self._decoder_names
 
-    def __getitem__(self, item):
-        if self.ENCODER_INITIALIZED and item in self._encoder_projectors._feature_names:
-            return self._encoder_projectors[item]
-        if self.DECODER_INITIALIZED and item in self._decoder_projectors._feature_names:
-            return self._decoder_projectors[item]
-        raise IndexError(item)
+    def __getitem__(self, tap: str) -> nn.Module:
+        for bank in self._banks():
+            if tap in bank:
+                return bank[tap]
+        raise IndexError(tap)
 
     def __iter__(self):
         if not (self.ENCODER_INITIALIZED and self.DECODER_INITIALIZED):
             raise RuntimeError(f"Encoder_projectors or Decoder_projectors are not initialized in {self.__class__.__name__}.")
-        yield from self._encoder_projectors
-        yield from self._decoder_projectors
+        for bank in self._banks():
+            yield from bank
 
 
 class IICLossWrapper(nn.Module):
+    """One criterion per tap: global ``IIDLoss`` on encoder taps, patch-averaged local MI with the tap's own displacement
+    range / patch size on decoder taps (ref _utils.py:178-224)."""
+
     def __init__(self, feature_names, paddings, patch_sizes) -> None:
         super().__init__()
-        feature_names = [feature_names] if isinstance(feature_names, str) else feature_names
-        self._encoder_features = _filter_encodernames(feature_names)
-        self._decoder_features = _filter_decodernames(feature_names)
-        assert len(feature_names) == len(self._encoder_features) + len(self._decoder_features)
-        self._LossModuleDict = nn.ModuleDict()
-        for f in self._encoder_features:
-            self._LossModuleDict[f] = IIDLoss()
-        if self._decoder_features:
-            n = _nlist(len(self._decoder_features))
-            for f, p, size in zip(self._decoder_features, n(paddings), n(patch_sizes)):
-                self._LossModuleDict[f] = IIDSegmentationSmallPathLoss(padding=p, patch_size=size)
+        names = _names(feature_names)
+        self._encoder_features, self._decoder_features = _on_side(names, "encoder"), _on_side(names, "decoder")
+        assert len(names) == len(self._encoder_features) + len(self._decoder_features), names
+        criteria = {tap: IIDLoss() for tap in self._encoder_features}
+        n = len(self._decoder_features)
+        if n:
+            for tap, pad, patch in zip(self._decoder_features, _per_tap(paddings, n, "paddings"), _per_tap(patch_sizes, n, "patch_sizes")):
+                criteria[tap] = IIDSegmentationSmallPathLoss(padding=pad, patch_size=patch)
+        self._LossModuleDict = nn.ModuleDict(criteria)
 
-    def __getitem__(self, item):
-        if item in self._LossModuleDict.keys():
-            return self._LossModuleDict[item]
-        raise IndexError(item)
+    def __getitem__(self, tap: str) -> nn.Module:
+        if tap not in self._LossModuleDict:
+            raise IndexError(tap)
+        return self._LossModuleDict[tap]
 
     def __iter__(self):
-        yield from self._LossModuleDict.values()
+        return iter(self._LossModuleDict.values())
 
     def items(self):
         return self._LossModuleDict.items()
 
     @property
-    def feature_names(self):
+    def feature_names(self) -> List[str]:
         return self._encoder_features + self._decoder_features

@@ -19,13 +19,30 @@ from semi_seg.synthetic import SyntheticEval, SyntheticPairs  # noqa: E402
 from semi_seg.trainer import trainer_zoos  # noqa: E402
 
 
-def main(argv=None):
+def _place_rank(config) -> int:
+    """One process per GPU (``python -m torch.distributed.run --nproc-per-node N semi_seg/main.py ...``): bind this process to
+    its own device BEFORE anything touches the GPU, point ``Trainer.device`` at it and join the RCCL job.  Returns the rank."""
+    import torch
+    from miseg_amd import ddp
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    wants_gpu = str(config["Trainer"].get("device", "cpu")).startswith("cuda")
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1 or os.environ.get("MISEG_FORCE_DDP", "0") == "1":
+        if wants_gpu:
+            torch.cuda.set_device(local)
+            config["Trainer"]["device"] = f"cuda:{local}"
+        ddp.init_from_env("nccl" if wants_gpu else "gloo")     # MISEG_DDP_BACKEND overrides (gloo also moves device tensors)
+    return int(os.environ.get("RANK", 0))
+
+
+def build_trainer(argv=None):
+    """Everything of ``main`` up to (not including) the training loop: config, rank placement, loaders, model, trainer,
+    optional checkpoint, data-parallel attachment."""
     cmanager = ConfigManger(Path(PROJECT_PATH) / "config/semi.yaml", argv=argv)
     config = cmanager.config
-    set_benchmark(config.get("RandomSeed", 1))
+    rank = _place_rank(config)
+    set_benchmark(config.get("RandomSeed", 1))     # identical initial weights on every rank; the data seeds below differ per rank
     size = int(config.get("Data", {}).get("size", 256))
     classes = config["Arch"]["num_classes"]
-    rank = int(os.environ.get("RANK", 0))
     data_root = config.get("Data", {}).get("root") or DATA_PATH
     data_name = config.get("Data", {}).get("name", "acdc")
     if data_name == "acdc" and (Path(data_root) / "ACDC_contrast").is_dir():
@@ -47,7 +64,18 @@ def main(argv=None):
     checkpoint = config.get("Checkpoint", None)
     if checkpoint is not None:
         trainer.load_state_dict_from_path(checkpoint, strict=False)
-    trainer.start_training()
+    trainer.attach_data_parallel()      # no-op for a single process; else bucketed RCCL all-reduce of the flat gradient
+    return trainer
+
+
+def main(argv=None):
+    trainer = build_trainer(argv)
+    try:
+        trainer.start_training()
+    finally:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
     return trainer
 
 

@@ -57,8 +57,9 @@ class StepState:
 def train_step(state: StepState, labeled_img: Tensor, labeled_tgt: Tensor, unlabeled_img: Tensor, seed: int,
                mode: str = "udaiic", feature_names=("Conv5", "Up_conv3", "Up_conv2"),
                feature_importance=(0.5, 0.25, 0.25), paddings=(1, 3), patch_sizes=(1024, 1024),
-               cons_weight: float = 5.0, iic_weight: float = 0.1, num_classes: int = 4, do_update: bool = True):
-    """Returns a dict of scalars (meter values) and, if requested, gradients by parameter name."""
+               cons_weight: float = 5.0, iic_weight: float = 0.1, num_classes: int = 4, do_update: bool = True, unet_fn=None):
+    """Returns a dict of scalars (meter values) and, if requested, gradients by parameter name.  ``unet_fn`` swaps the network
+    evaluation (default ``oracle.unet.unet_forward``; ``unet_forward_bf16_autograd`` emulates the bf16 kernels' rounding points)."""
     params = state.params()
     for p in params:
         p.requires_grad_(True)
@@ -66,7 +67,7 @@ def train_step(state: StepState, labeled_img: Tensor, labeled_tgt: Tensor, unlab
     lb, ub = labeled_img.shape[0], unlabeled_img.shape[0]
     decisions = L.flip_decisions(seed, ub)
     unlabeled_tf = L.apply_flips(unlabeled_img, decisions)                       # epocher.py:148-149
-    logits, feats = U.unet_forward(state.model, torch.cat([labeled_img, unlabeled_img, unlabeled_tf], 0), True)
+    logits, feats = (unet_fn or U.unet_forward)(state.model, torch.cat([labeled_img, unlabeled_img, unlabeled_tf], 0), True)
     label_logits, unlabel_logits, unlabel_tf_logits = torch.split(logits, [lb, ub, ub], 0)
     unlabel_logits_tf = L.apply_flips(unlabel_logits, decisions)                 # epocher.py:160-161
     onehot = L.class2one_hot(labeled_tgt.squeeze(1), num_classes)

@@ -146,3 +146,50 @@ def unet_forward_bf16_emulated(sd, x: Tensor):
         u = cbr(F.interpolate(d, scale_factor=2, mode="nearest"), f"Up{lvl}.up.1", f"Up{lvl}.up.2")
         d = block(f"Up_conv{lvl}", torch.cat((skip, u), 1))
     return F.conv2d(d, sd["DeConv_1x1.weight"], sd["DeConv_1x1.bias"])
+
+
+class _RoundBF16(torch.autograd.Function):
+    """bf16 rounding point of a stored tensor: the value is rounded going forward, its gradient going backward (the HIP path
+    stores activation gradients in bf16 too); ``grad=False`` = a weight operand (its gradient stays fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, grad):
+        ctx.round_grad = grad
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.bfloat16().float() if ctx.round_grad else g), None
+
+
+def unet_forward_bf16_autograd(sd, x: Tensor, training: bool = True, update_stats: bool = False):
+    """:func:`unet_forward` with the bf16 kernels' rounding points (see :func:`unet_forward_bf16_emulated`) as differentiable
+    straight-through roundings, so that autograd yields the gradients the bf16 HIP step computes up to accumulation order and
+    ReLU-mask flips: operands bf16, accumulation and batch statistics fp32, raw conv output / activations / their gradients
+    stored in bf16, weight gradients and logits fp32.  Same return value as unet_forward.  No buffers are updated."""
+    assert training
+    r = _RoundBF16.apply
+    f: "OrderedDict[str, Tensor]" = OrderedDict()
+
+    def cbr(t, ck, bk):
+        acc = F.conv2d(t, r(sd[f"{ck}.weight"], False), None, 1, 1)
+        mean = acc.mean((0, 2, 3), keepdim=True)
+        var = acc.var((0, 2, 3), unbiased=False, keepdim=True)
+        scale = sd[f"{bk}.weight"].view(1, -1, 1, 1) * torch.rsqrt(var + BN_EPS)
+        shift = sd[f"{bk}.bias"].view(1, -1, 1, 1) - mean * scale
+        return r(F.relu(r(acc, True) * scale + shift), True)
+
+    def block(name, t):
+        return cbr(cbr(t, f"{name}.conv.0", f"{name}.conv.1"), f"{name}.conv.3", f"{name}.conv.4")
+
+    pool = lambda t: F.max_pool2d(t, 2, 2)  # noqa: E731
+    e1 = f["Conv1"] = block("Conv1", r(x, False))
+    e2 = f["Conv2"] = block("Conv2", pool(e1))
+    e3 = f["Conv3"] = block("Conv3", pool(e2))
+    e4 = f["Conv4"] = block("Conv4", pool(e3))
+    d = f["Conv5"] = block("Conv5", pool(e4))
+    for lvl, skip in ((5, e4), (4, e3), (3, e2), (2, e1)):
+        u = f[f"Up{lvl}"] = cbr(F.interpolate(d, scale_factor=2, mode="nearest"), f"Up{lvl}.up.1", f"Up{lvl}.up.2")
+        d = f[f"Up_conv{lvl}"] = block(f"Up_conv{lvl}", torch.cat((skip, u), 1))
+    logits = f["DeConv_1x1"] = F.conv2d(d, sd["DeConv_1x1.weight"], sd["DeConv_1x1.bias"])
+    return logits, f

@@ -70,3 +70,49 @@ def test_grad_reducer_matches_single_process(tmp_path):
         grads.append(flat.flat_grad.clone())
     torch.testing.assert_close(r0["grad"], (grads[0] + grads[1]) / 2, rtol=1e-6, atol=1e-7)
     assert float(r0["grad"][-12:].abs().max()) == 0.0   # the unused layer's slot stays exactly zero
+
+
+# ------------------------------------------------------------------------------------------ through the entry point
+def _main_worker(rank, world, port, out_dir):
+    """``semi_seg/main.py``'s own wiring (build_trainer = main minus the loop) in a 2-rank gloo job on CPU tensors: rank
+    placement, process group, trainer construction, GradReducer attachment, rank-0-only run directory.  The kernels are GPU-only,
+    so the gradient that travels is produced by a surrogate loss on the real parameters (each rank scales it differently)."""
+    sys.path.insert(0, SRC)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MISEG_PROGRESS="0")
+    from semi_seg.main import build_trainer
+    save_dir = os.path.join(out_dir, "run")      # the SAME directory on both ranks, as in a real job
+    trainer = build_trainer(["Trainer.name=udaiic", "Trainer.device=cpu", f"Trainer.save_dir={save_dir}", "Trainer.max_epoch=1",
+                             "Trainer.num_batches=1", "Data.name=synthetic", "Data.size=32", "LabeledData.batch_size=1",
+                             "UnlabeledData.batch_size=1"])
+    assert dist.is_initialized() and dist.get_world_size() == world and dist.get_backend() == "gloo"
+    red = trainer._grad_reducer
+    assert red is not None and red.world == world and trainer.is_writer == (rank == 0)
+    flat = trainer._optimizer.flat
+    assert red.flat is flat and flat.flat_param.numel() > 2_000_000      # U-Net + the 15 projector sub-heads in ONE buffer
+    for _ in range(2):
+        trainer._optimizer.zero_grad()
+        red.prepare()
+        params = list(trainer._model.parameters()) + list(trainer._projector_wrappers.parameters())
+        sum(((rank + 1.0) * 0.5 * (p ** 2).sum()) for p in params).backward()     # d/dp = (rank + 1) p
+        red.finish()
+    # the trainer's own logging / checkpoint path: every rank calls it, only the writer touches the directory
+    from deepclustering2.meters2 import StorageIncomeDict
+    trainer._cur_epoch = 0
+    with trainer._writer_context() as trainer._writer:
+        trainer._log_epoch(StorageIncomeDict(tra={"loss": {"mean": 1.0}}, val={"loss": {"mean": 2.0}}, test={"loss": {"mean": 3.0}}), 0.5)
+    assert trainer._best_score == 0.5
+    torch.save({"grad": flat.flat_grad.clone(), "param": flat.flat_param.clone()}, os.path.join(out_dir, f"m{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_main_entry_point_wires_data_parallel(tmp_path):
+    world, port = 2, 31500 + os.getpid() % 2000
+    mp.spawn(_main_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"m{r}.pt") for r in range(world))
+    torch.testing.assert_close(r0["param"], r1["param"], rtol=0, atol=0)      # same seed + broadcast
+    torch.testing.assert_close(r0["grad"], r1["grad"], rtol=0, atol=0)
+    torch.testing.assert_close(r0["grad"], 1.5 * r0["param"], rtol=1e-6, atol=1e-9)    # mean of (1 p, 2 p)
+    run = tmp_path / "run"
+    assert sorted(p.name for p in run.iterdir() if p.suffix in (".pth", ".yaml", ".csv")) == ["best.pth", "config.yaml", "last.pth", "storage.csv"]

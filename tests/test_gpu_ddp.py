@@ -1,0 +1,51 @@
+"""GPU, two processes on the box's one GPU, gloo: the data-parallel path of the REAL train step.
+
+What the design depends on and a toy model cannot show (tests/test_cpu_ddp.py covers the bucketing itself): parameter gradients
+are written into their flat-buffer slots from three HIP streams (main backward, IIC branch, weight-gradient side stream), the
+reducer's buckets are launched from post-accumulate hooks while the backward is still running, and a bucket must first join every
+producer stream (`GradReducer._launch`, `FlatBuffers.collect` -> `join_wgrad_streams`).  Each rank runs one udaiic step of
+UDAIICEpocher on its own batch; the all-reduced flat gradient must equal the mean of the two single-process runs on those batches."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_ddp_step_worker.py")
+
+
+def _run(args, env=None, timeout=600):
+    return subprocess.Popen([sys.executable, WORKER] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_two_rank_step_reduces_to_the_mean_of_the_shard_gradients(tmp_path, dtype):
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    singles = []
+    for r in range(2):          # single-process shard runs, one after the other
+        p = _run([r, tmp_path / f"single{r}.pt", dtype], env=base)
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+        singles.append(torch.load(tmp_path / f"single{r}.pt"))
+    port = 32500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):          # the 2-rank job: both ranks on cuda:0, collectives over gloo
+        env = dict(base, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MISEG_DDP_BACKEND="gloo")
+        procs.append(_run([r, tmp_path / f"ddp{r}.pt", dtype], env=env))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    d0, d1 = (torch.load(tmp_path / f"ddp{r}.pt") for r in range(2))
+    assert d0["buckets"] == 3 and d0["streams"] >= 2                 # the IIC side stream registered itself as a producer
+    assert torch.equal(d0["grad"], d1["grad"])                       # identical on both ranks after the all-reduce
+    assert torch.equal(d0["param_after"], d1["param_after"])         # ... and so is the optimiser step
+    mean = (singles[0]["grad"].double() + singles[1]["grad"].double()) / 2
+    got = d0["grad"].double()
+    # same kernels, same inputs per rank: the only difference is (a + b) / 2 in fp32 on the host path of gloo
+    err = float((got - mean).abs().max())
+    scale = float(mean.abs().max())
+    assert err <= 2e-6 * scale, (err, scale)
+    assert float((singles[0]["grad"] - singles[1]["grad"]).abs().max()) > 1e-3 * scale     # the shards really differ

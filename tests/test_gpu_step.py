@@ -225,22 +225,40 @@ def test_step_gradients_match_reference(golden, monkeypatch, mode, wgrad_side, i
     rows = _gradient_errors(g, mode, grads)
     _dump(f"{mode}_fp32_w{int(wgrad_side)}i{int(iic_side)}", rows)
     worst = {k: v[0] for k, v in rows.items()}
-    bad = {k: v for k, v in worst.items() if v > 5e-2 and rows[k][2] > 1e-7}     # 1e-7: the global-MI heads' gradients are fp32 noise
+    # measured (round 2, gpurun_out/step_grad_errors_*): last block / logits layer 2e-7 .. 3e-4 (median 7e-6), decoder-tap heads
+    # <= 3e-5, everything behind more ReLUs 1e-3 .. 1.2e-2; the bounds below leave ~3x of that
+    bad = {k: v for k, v in worst.items() if v > 3e-2 and rows[k][2] > 1e-7}     # <= 1e-7: the global-MI head's gradients are fp32 noise
     assert not bad, bad
     tail = sorted(v for k, v in worst.items() if k.startswith(("Up_conv2", "DeConv")))
-    assert tail[len(tail) // 2] < 2e-3 and tail[0] < 2e-4, tail
+    assert tail[len(tail) // 2] < 1e-4 and tail[0] < 1e-5 and tail[-1] < 2e-3, tail
     if mode == "udaiic":
         dec_heads = sorted(v for k, v in worst.items() if "_decoder_projectors" in k)
-        assert dec_heads[-1] < 2e-2 and dec_heads[len(dec_heads) // 2] < 5e-3, dec_heads
-    # a wrong sign, a missing term or a stale slot shows up as rel_l2 ~ 1 or 2: nothing may be anywhere near that
-    assert max(v for k, v in worst.items() if rows[k][2] > 1e-7) < 0.1
+        assert dec_heads[-1] < 2e-4, dec_heads
 
 
-def test_step_gradients_bf16_track_reference(golden, monkeypatch):
-    """The same comparison in the bench's arithmetic (bf16 activations, bf16x3 local MI): bf16 rounding of 23 layers of a
-    random-init net bounds what is reachable (the forward logits differ by ~17 % RMS, test_unet_256_fp32_and_bf16), so this guards
-    orchestration (sign / missing term / stale slot => rel_l2 >= 1) and records the achieved errors."""
+def _oracle_names(g, mode):
+    """oracle parameter name ('<tap>/_headers...') -> reference optimiser name ('proj/_decoder_projectors._clusters.<tap>...')."""
+    pref = {"Conv5": "proj/_encoder_projectors._clusters.Conv5.", "Up_conv3": "proj/_decoder_projectors._clusters.Up_conv3.",
+            "Up_conv2": "proj/_decoder_projectors._clusters.Up_conv2."}
+
+    def to_ref(n):
+        if "/" not in n:
+            return n
+        f, k = n.split("/", 1)
+        return pref[f] + k
+    return to_ref
+
+
+def test_step_gradients_bf16_match_bf16_emulation_and_track_reference(golden, monkeypatch):
+    """The bench's arithmetic (bf16 activations and activation gradients, bf16x3 local MI), iteration-1 gradients of every
+    parameter against
+      (a) the CPU oracle step with the SAME rounding points (oracle.unet.unet_forward_bf16_autograd: straight-through bf16
+          roundings of every stored tensor): only accumulation order and ReLU-mask / pool-tie flips differ -> must be close;
+      (b) the reference's fp32 gradients (step.npz): on this random-init net, forward bf16 rounding alone moves the gradient of
+          Up_conv2.conv.3 by 18 % and of Conv1 by 80 % (the CPU emulation shows the same profile: scratch analysis recorded in
+          DESIGN.md section 2) -- so (b) only guards against gross errors and records the achieved figures."""
     from miseg_amd import ops as _ops
+    from oracle import step as OS
     g = golden("step")
     _ops.set_mi_precision("bf16x3")
     try:
@@ -248,11 +266,31 @@ def test_step_gradients_bf16_track_reference(golden, monkeypatch):
     finally:
         _ops.set_mi_precision("fp32")
     rows = _gradient_errors(g, "udaiic", grads)
-    _dump("udaiic_bf16", rows)
+    _dump("udaiic_bf16_vs_fp32_reference", rows)
     sig = {k: v[0] for k, v in rows.items() if v[2] > 1e-7}
-    assert max(sig.values()) < 0.6, {k: v for k, v in sig.items() if v >= 0.6}
-    vals = sorted(sig.values())
-    assert vals[len(vals) // 2] < 0.15, vals[len(vals) // 2]
+    assert max(sig.values()) < 1.3, {k: v for k, v in sig.items() if v >= 1.3}
+    assert sig["DeConv_1x1.weight"] < 3e-2 and sig["Up_conv2.conv.3.weight"] < 0.3
+    # (a) same rounding points on the CPU
+    H, LB, UB = STEP["H"], STEP["LB"], STEP["UB"]
+    heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=10), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=11),
+             "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=12)}
+    state = OS.StepState(OU.init_state(1, 4, seed=9), heads, lr=STEP["lr"], weight_decay=STEP["wd"])
+    limg = T(synth.uniform("step/udaiic/lab0", (LB, 1, H, H)))
+    ltgt = T(synth.integers("step/udaiic/tgt0", (LB, 1, H, H), 4))
+    uimg = T(synth.uniform("step/udaiic/unl0", (UB, 1, H, H)))
+    _, emu = OS.train_step(state, limg, ltgt, uimg, int(g["udaiic/seeds"][0]), mode="udaiic", cons_weight=STEP["cons_weight"],
+                           iic_weight=STEP["iic_weight"], do_update=False, unet_fn=OU.unet_forward_bf16_autograd)
+    to_ref = _oracle_names(g, "udaiic")
+    emu_rows = {}
+    for n, ge in emu.items():
+        mine, ref = grads[to_ref(n)].astype(np.float64), ge.numpy().astype(np.float64)
+        emu_rows[to_ref(n)] = (float(np.linalg.norm(mine - ref) / (np.linalg.norm(ref) + 1e-30)),
+                               float(np.abs(mine - ref).max() / (np.abs(ref).max() + 1e-30)), float(np.abs(ref).max()))
+    _dump("udaiic_bf16_vs_bf16_emulation", emu_rows)
+    sig = {k: v[0] for k, v in emu_rows.items() if v[2] > 1e-7}
+    assert max(sig.values()) < 0.25, {k: v for k, v in sig.items() if v >= 0.25}
+    tail = sorted(v for k, v in sig.items() if k.startswith(("Up_conv2", "DeConv")) or "_decoder_projectors" in k)
+    assert tail[len(tail) // 2] < 2e-2, tail
 
 
 def test_deferred_readback_records_every_iteration_like_the_synchronous_one():
