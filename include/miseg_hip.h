@@ -106,6 +106,13 @@ int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S
 int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K,
                          float lamb, const float* upstream, float* gx, float* gy);
 
+/* compute_joint on its own (ref iic_loss.py:74-94): joint [S][K][K] = normalised sum_n x_n (x) y_n, symmetrised iff `symmetric`;
+ * bwd: gjoint = dL/djoint -> gx, gy [S][N][K]. */
+int miseg_iic_global_joint_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, int symmetric,
+                               float* joint);
+int miseg_iic_global_joint_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, int symmetric,
+                               const float* joint, const float* gjoint, float* gx, float* gy);
+
 /* ------------------------------------------------------------------------------------------
  * Cluster heads
  * ref: contrastyou/trainer/_utils.py:137-168 (LocalClusterHead: 1x1 conv C->K + bias, channel
@@ -139,6 +146,30 @@ int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W,
                           const float* prob, const float* gprob, void* gfeat, float* gw, float* gb,
                           float* dz_ws /* fp32[S*M*K] scratch */);
 
+/* Head VARIANTS of the same two classes (csrc/heads_var.hip): head_type="mlp" (ref contrastyou/trainer/_utils.py:117-126 global,
+ * :154-161 local: Linear/1x1-conv C->HID, LeakyReLU(0.01), Linear/1x1-conv HID->K; HID = 128 global, interm_dim = 64 local) and
+ * normalize=True (ref :26-33, :113, :123, :150, :158: logits L2-normalised over the class axis, eps 1e-12, before softmax(./T)).
+ * HID == 0 selects the single-layer head: w1 fp32 [S][K][C], b1 [S][K], w2/b2 unused (NULL).  HID > 0: w1 [S][HID][C], b1 [S][HID],
+ * w2 [S][K][HID], b2 [S][K].  Same gather (src) / flip replay (flips) / layouts / gfeat contract as the linear entry points above;
+ * the backward recomputes the forward from the features (nothing but the features is saved), gw1/gb1/gw2/gb2 are overwritten. */
+int miseg_head_local_var_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                             const int32_t* src, const int32_t* flips, int64_t M, const float* w1, const float* b1,
+                             int64_t HID, const float* w2, const float* b2, int64_t S, int64_t K, float T, int normalize,
+                             float* prob);
+int64_t miseg_head_local_var_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t HID, int64_t S, int64_t K);
+int miseg_head_local_var_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                             const int32_t* src, const int32_t* flips, int64_t M, const float* w1, const float* b1,
+                             int64_t HID, const float* w2, const float* b2, int64_t S, int64_t K, float T, int normalize,
+                             const float* gprob, void* gfeat, float* gw1, float* gb1, float* gw2, float* gb2, void* ws,
+                             int64_t ws_bytes);
+int miseg_head_global_var_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                              const int32_t* src, int64_t M, const float* w1, const float* b1, int64_t HID, const float* w2,
+                              const float* b2, int64_t S, int64_t K, float T, int normalize, float* pooled, float* prob);
+int miseg_head_global_var_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src, int64_t M,
+                              const float* w1, const float* b1, int64_t HID, const float* w2, const float* b2, int64_t S,
+                              int64_t K, float T, int normalize, const float* pooled, const float* gprob, void* gfeat,
+                              float* gw1, float* gb1, float* gw2, float* gb2, float* dpool_ws /* fp32[S*M*C] scratch */);
+
 /* ------------------------------------------------------------------------------------------
  * Pixel-wise losses on logits (fp32 NHWC [N,H,W,C], C <= 32)
  * softmax_kl : ref whl:deepclustering2/loss/kl_losses.py:107-126 on softmax(logits)
@@ -148,9 +179,14 @@ int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W,
  *              A label outside [0,C) sets *bad_label (int32) != 0 (the reference asserts).
  * softmax_mse: ref semi_seg/epocher.py:221-224 -- mean((softmax(a) - softmax(flip(b)))^2) over all
  *              elements, b detached; flip(b) per `flips` is index math.  ga = upstream * d/da.
+ * softmax_klcons: the `UDARegCriterion.name: kl` form of the same term (ref semi_seg/trainer.py:137,194 with
+ *              whl:deepclustering2/loss/kl_losses.py:107-126): mean_{n,h,w} sum_c -t*log((p+1e-16)/(t+1e-16)),
+ *              p = softmax(a), t = softmax(flip(b)) detached.  Same arguments as softmax_mse.
  * `upstream` = fp32 device scalar (may be NULL = 1.0).  Results are deterministic (two-pass sums).
  * ------------------------------------------------------------------------------------------ */
 int64_t miseg_loss_ws_bytes(int64_t N, int64_t H, int64_t W);
+int miseg_softmax_klcons(void* stream, const float* a, const float* b, const int32_t* flips, int64_t N, int64_t H,
+                         int64_t W, int64_t C, const float* upstream, float* loss, float* ga, void* ws, int64_t ws_bytes);
 int miseg_softmax_kl(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
                      int64_t C, const float* upstream, float* loss, float* glogits, int32_t* bad_label, void* ws,
                      int64_t ws_bytes);

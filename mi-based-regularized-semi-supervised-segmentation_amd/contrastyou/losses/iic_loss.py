@@ -49,14 +49,12 @@ class IIDLoss(nn.Module):
 
 
 def compute_joint(x_out: Tensor, x_tf_out: Tensor, symmetric: bool = True) -> Tensor:
-    """ref iic_loss.py:74-94 (symmetric=True is the only mode the hot path uses and the kernel provides)."""
+    """ref iic_loss.py:74-94: normalised sum_n x_n (outer) y_n, symmetrised unless ``symmetric=False``; differentiable."""
     checks.assert_simplex(x_out, 1, "x_out not normalized.")
     checks.assert_simplex(x_tf_out, 1, "x_tf_out not normalized.")
     bn, k = x_out.shape
     assert x_tf_out.size(0) == bn and x_tf_out.size(1) == k
-    if not symmetric:
-        raise NotImplementedError("compute_joint(symmetric=False) is not on the hot path")
-    return ops.global_mi(x_out.unsqueeze(0), x_tf_out.unsqueeze(0), 1.0)[2][0]
+    return ops.global_joint(x_out.unsqueeze(0), x_tf_out.unsqueeze(0), symmetric)[0]
 
 
 def _windows(h: int, w: int, patch, step):

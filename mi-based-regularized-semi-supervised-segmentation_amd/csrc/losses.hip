@@ -85,6 +85,45 @@ __global__ __launch_bounds__(kLT) void softmax_mse_kernel(const float* __restric
     if (threadIdx.x == 0) partials[blockIdx.x] = part;
 }
 
+// KL variant of the consistency term (ref semi_seg/trainer.py:137,194 `UDARegCriterion.name: kl`, semi_seg/epocher.py:221-224 with
+// whl:deepclustering2/loss/kl_losses.py:107-126):  mean_pix sum_c -t_c log((p_c + eps) / (t_c + eps)),  p = softmax(a),
+// t = softmax(flip(b)) detached, eps = 1e-16.  d/da_c = p_c (g_c - <g, p>) with g_c = -t_c / (p_c + eps).
+template <int C>
+__global__ __launch_bounds__(kLT) void softmax_klcons_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const int32_t* __restrict__ flips, int H, int W, int64_t npix,
+                                                             const float* __restrict__ upstream, float* __restrict__ partials,
+                                                             float* __restrict__ ga) {
+    __shared__ float red[17];
+    const float up = (upstream ? upstream[0] : 1.f) / (float)npix;
+    const float eps = 1e-16f;
+    const int64_t HW = (int64_t)H * W;
+    float part = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)kLT + threadIdx.x; i < npix; i += (int64_t)gridDim.x * kLT) {
+        const int n = i / HW, rem = i % HW, h = rem / W, w = rem % W;
+        const int f = flips ? flips[n] : 0;
+        const int64_t j = (int64_t)n * HW + (int64_t)flip_h(h, H, f) * W + flip_w(w, W, f);
+        float za[C], zb[C], pa[C], pb[C], g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { za[c] = a[i * C + c]; zb[c] = b[j * C + c]; }
+        softmax_c(za, C, pa);
+        softmax_c(zb, C, pb);
+        float kl = 0.f, dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            kl += -pb[c] * logf((pa[c] + eps) / (pb[c] + eps));
+            g[c] = -pb[c] / (pa[c] + eps);
+            dot += g[c] * pa[c];
+        }
+        part += kl;
+        if (ga) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) ga[i * C + c] = up * pa[c] * (g[c] - dot);
+        }
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = part;
+}
+
 __global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out) {
     __shared__ float red[17];
     // independent loads first (a dependent load-add chain over 8 partials per thread was ~50 us of pure latency), fixed order
@@ -218,6 +257,22 @@ extern "C" int miseg_softmax_mse(void* stream, const float* a, const float* b, c
 #undef L
     MISEG_LAUNCH_CHECK("softmax_mse_kernel");
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, 1.0f / ((float)npix * (float)C), loss);
+    MISEG_LAUNCH_CHECK("finish_sum_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_softmax_klcons(void* stream, const float* a, const float* b, const int32_t* flips, int64_t N, int64_t H, int64_t W,
+                                    int64_t C, const float* upstream, float* loss, float* ga, void* ws, int64_t ws_bytes) {
+    MISEG_REQUIRE(a && b && loss && ws, "softmax_klcons: null pointer");
+    const int64_t npix = N * H * W;
+    MISEG_REQUIRE(npix > 0 && ws_bytes >= miseg_loss_ws_bytes(N, H, W), "softmax_klcons: bad shape / workspace");
+    const int nb = loss_blocks(npix);
+    hipStream_t st = as_stream(stream);
+#define L(CC) hipLaunchKernelGGL(softmax_klcons_kernel<CC>, dim3(nb), dim3(kLT), 0, st, a, b, flips, (int)H, (int)W, npix, upstream, (float*)ws, ga)
+    MISEG_DISPATCH_C(C, L)
+#undef L
+    MISEG_LAUNCH_CHECK("softmax_klcons_kernel");
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, 1.0f / (float)npix, loss);
     MISEG_LAUNCH_CHECK("finish_sum_kernel");
     return MISEG_OK;
 }

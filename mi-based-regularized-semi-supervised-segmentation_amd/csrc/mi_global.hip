@@ -221,9 +221,93 @@ __global__ __launch_bounds__(256) void head_global_bwd_feat_kernel(const float* 
     }
 }
 
+// compute_joint (ref iic_loss.py:74-94) on its own, with the reference's `symmetric` switch: P = sum_n x_n (x) y_n, optionally
+// (P + P^T) / 2, divided by its sum.  IIDLoss always symmetrises (the fused kernels above); this pair serves direct callers.
+__global__ __launch_bounds__(256) void iic_joint_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, int N, int K,
+                                                            int symmetric, float* __restrict__ joint) {
+    __shared__ float Ps[kMaxK * kMaxK];
+    __shared__ float red[17];
+    const int s = blockIdx.x, KK = K * K;
+    const float* x = xs + (size_t)s * N * K;
+    const float* y = ys + (size_t)s * N * K;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        const int i = e / K, j = e % K;
+        float a = 0.f, t = 0.f;
+        for (int n = 0; n < N; ++n) {
+            a += x[n * K + i] * y[n * K + j];
+            t += x[n * K + j] * y[n * K + i];
+        }
+        Ps[e] = symmetric ? (a + t) / 2.0f : a;
+    }
+    __syncthreads();
+    float z = 0.f;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) z += Ps[e];
+    z = block_sum(z, red);
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) joint[(size_t)s * KK + e] = Ps[e] / z;
+}
+
+// given G = dL/dP:  dL/dQ = (G - <G, P>) / Z with Q the (symmetrised) raw joint; the raw outer-product sum J enters Q as
+// (J + J^T)/2 when symmetric -> dL/dJ = (D + D^T)/2, else D;  gx[n,i] = sum_j dJ[i][j] y[n,j],  gy[n,j] = sum_i dJ[i][j] x[n,i].
+__global__ __launch_bounds__(256) void iic_joint_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, int N, int K,
+                                                            int symmetric, const float* __restrict__ joint, const float* __restrict__ gjoint,
+                                                            float* __restrict__ gxs, float* __restrict__ gys) {
+    __shared__ float D[kMaxK * kMaxK];
+    __shared__ float red[17];
+    const int s = blockIdx.x, KK = K * K;
+    const float* x = xs + (size_t)s * N * K;
+    const float* y = ys + (size_t)s * N * K;
+    const float* P = joint + (size_t)s * KK;
+    const float* G = gjoint + (size_t)s * KK;
+    float z = 0.f;                                   // Z = sum_n (sum_i x)(sum_j y), symmetric or not
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float sx = 0.f, sy = 0.f;
+        for (int k = 0; k < K; ++k) { sx += x[n * K + k]; sy += y[n * K + k]; }
+        z += sx * sy;
+    }
+    z = block_sum(z, red);
+    float dot = 0.f;
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) dot += G[e] * P[e];
+    dot = block_sum(dot, red);
+    for (int e = threadIdx.x; e < KK; e += blockDim.x) {
+        const int i = e / K, j = e % K;
+        const float d = (G[e] - dot) / z, dt = (G[j * K + i] - dot) / z;
+        D[e] = symmetric ? (d + dt) / 2.0f : d;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+        const int n = e / K, k = e % K;
+        float ax = 0.f, ay = 0.f;
+        for (int t = 0; t < K; ++t) {
+            ax += D[k * K + t] * y[n * K + t];
+            ay += D[t * K + k] * x[n * K + t];
+        }
+        gxs[(size_t)s * N * K + e] = ax;
+        gys[(size_t)s * N * K + e] = ay;
+    }
+}
+
 }  // namespace miseg
 
 using namespace miseg;
+
+extern "C" int miseg_iic_global_joint_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, int symmetric,
+                                          float* joint) {
+    MISEG_REQUIRE(x && y && joint, "iic_global_joint_fwd: null pointer");
+    MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_joint_fwd: need 0<K<=%d", kMaxK);
+    hipLaunchKernelGGL(iic_joint_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, symmetric, joint);
+    MISEG_LAUNCH_CHECK("iic_joint_fwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_global_joint_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, int symmetric,
+                                          const float* joint, const float* gjoint, float* gx, float* gy) {
+    MISEG_REQUIRE(x && y && joint && gjoint && gx && gy, "iic_global_joint_bwd: null pointer");
+    MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_joint_bwd: need 0<K<=%d", kMaxK);
+    hipLaunchKernelGGL(iic_joint_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, symmetric, joint, gjoint,
+                       gx, gy);
+    MISEG_LAUNCH_CHECK("iic_joint_bwd_kernel");
+    return MISEG_OK;
+}
 
 extern "C" int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, float lamb,
                                     float* loss, float* loss_no_lamb, float* joint) {

@@ -31,6 +31,8 @@ class _NullWriter:
         return False
 
     def __getattr__(self, name):
+        if not name.startswith(("add_", "close", "flush")):      # in particular no state_dict: it must not show up in checkpoints
+            raise AttributeError(name)
         return lambda *a, **k: None
 
 

@@ -134,7 +134,11 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
         if amsgrad:
             raise NotImplementedError("amsgrad is not implemented in the fused HIP Adam")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        # the remaining keys are torch.optim.Adam's own defaults: carried so that param_groups -- hence checkpoints -- have the
+        # key set a torch Adam of this torch version writes (reference checkpoints load key for key, and ours load there)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self._flats: List[FlatBuffers] = [FlatBuffers(list(g["params"])) for g in self.param_groups]
         self._steps = [0 for _ in self.param_groups]
         self._m: List[Optional[Tensor]] = [None] * len(self.param_groups)

@@ -292,6 +292,34 @@ def global_mi(x: Tensor, y: Tensor, lamb: float = 1.0):
     return _GlobalMI.apply(x, y, float(lamb))
 
 
+class _GlobalJoint(torch.autograd.Function):
+    """compute_joint (ref iic_loss.py:74-94) for S pairs at once: x, y [S,N,K] -> joint [S,K,K]."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, y: Tensor, symmetric: bool):
+        _need_gpu(x, y)
+        x, y = x.contiguous().float(), y.contiguous().float()
+        s, n, k = x.shape
+        joint = torch.empty(s, k, k, dtype=torch.float32, device=x.device)
+        call("miseg_iic_global_joint_fwd", _stream(), _ptr(x), _ptr(y), s, n, k, int(bool(symmetric)), _ptr(joint))
+        ctx.save_for_backward(x, y, joint)
+        ctx.symmetric = bool(symmetric)
+        return joint
+
+    @staticmethod
+    def backward(ctx, gjoint):
+        x, y, joint = ctx.saved_tensors
+        s, n, k = x.shape
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        gjoint = gjoint.contiguous().float()
+        call("miseg_iic_global_joint_bwd", _stream(), _ptr(x), _ptr(y), s, n, k, int(ctx.symmetric), _ptr(joint), _ptr(gjoint), _ptr(gx), _ptr(gy))
+        return gx, gy, None
+
+
+def global_joint(x: Tensor, y: Tensor, symmetric: bool = True) -> Tensor:
+    return _GlobalJoint.apply(x, y, bool(symmetric))
+
+
 # ------------------------------------------------------------------------------------------ heads
 def as_nhwc(t: Tensor) -> Tensor:
     """[N,C,H,W]-shaped tensor whose memory is NHWC (channels_last); converts if needed."""
@@ -420,6 +448,102 @@ def global_head(feat: Tensor, w: Tensor, b: Tensor, src: Tensor, temperature: fl
     return _GlobalHead.apply(feat, w, b, src, float(temperature))
 
 
+# ------------------------------------------------------------------------------------------ head variants (mlp / normalize)
+class _LocalHeadVar(torch.autograd.Function):
+    """LocalClusterHead with head_type='mlp' and/or normalize=True (csrc/heads_var.hip) -> prob [S,M,K,H,W].
+    hid == 0: single layer (w1 [S,K,C], b1 [S,K]; w2, b2 are dummies).  The backward recomputes the forward from the features."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, src, flips, temperature: float, normalize: bool, hid: int):
+        _need_gpu(feat, w1, b1, src, flips)
+        feat = as_nhwc(feat)
+        bsz, c, h, wd = feat.shape
+        s = w1.shape[0]
+        k = (w2 if hid else w1).shape[1]
+        m = src.numel()
+        ctx.stacks = tuple(getattr(t, "_miseg_stack_params", None) for t in (w1, b1, w2, b2))
+        w1, b1 = w1.contiguous().float(), b1.contiguous().float()
+        w2, b2 = (w2.contiguous().float(), b2.contiguous().float()) if hid else (None, None)
+        prob = torch.empty(s, m, k, h, wd, dtype=torch.float32, device=feat.device)
+        call("miseg_head_local_var_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w1), _ptr(b1),
+             hid, _ptr(w2), _ptr(b2), s, k, float(temperature), int(bool(normalize)), _ptr(prob))
+        ctx.save_for_backward(feat, w1, b1, w2, b2, src, flips)
+        ctx.cfg = (float(temperature), bool(normalize), int(hid), k)
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        feat, w1, b1, w2, b2, src, flips = ctx.saved_tensors
+        temperature, normalize, hid, k = ctx.cfg
+        bsz, c, h, wd = feat.shape
+        s, m, dev = w1.shape[0], src.numel(), feat.device
+        gprob = gprob.contiguous().float()
+        gfeat = zeros_nhwc(bsz, c, h, wd, feat.dtype, dev) if ctx.needs_input_grad[0] else None
+        gw1 = _stacked_grad(ctx.stacks[0], w1.shape, dev)
+        gb1 = _stacked_grad(ctx.stacks[1], b1.shape, dev)
+        gw2 = _stacked_grad(ctx.stacks[2], w2.shape, dev) if hid else None
+        gb2 = _stacked_grad(ctx.stacks[3], b2.shape, dev) if hid else None
+        ws = _ws(query("miseg_head_local_var_bwd_ws_bytes", m, h, wd, c, hid, s, k), dev)
+        call("miseg_head_local_var_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w1), _ptr(b1),
+             hid, _ptr(w2), _ptr(b2), s, k, temperature, int(normalize), _ptr(gprob), _ptr(gfeat), _ptr(gw1), _ptr(gb1), _ptr(gw2), _ptr(gb2),
+             _ptr(ws), ws.numel())
+        return gfeat, gw1, gb1, gw2, gb2, None, None, None, None, None
+
+
+def local_head_var(feat, w1, b1, w2, b2, src, flips, temperature=1.0, normalize=False) -> Tensor:
+    """w2 is None for the single-layer head.  w1 [S,R,C] (R = hidden width or K), w2 [S,K,HID]."""
+    hid = 0 if w2 is None else int(w1.shape[1])
+    if w2 is None:
+        w2 = b2 = torch.empty(0, device=feat.device)
+    return _LocalHeadVar.apply(feat, w1, b1, w2, b2, src, flips, float(temperature), bool(normalize), hid)
+
+
+class _GlobalHeadVar(torch.autograd.Function):
+    """ClusterHead with head_type='mlp' and/or normalize=True -> prob [S,M,K]."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, src, temperature: float, normalize: bool, hid: int):
+        _need_gpu(feat, w1, b1, src)
+        feat = as_nhwc(feat)
+        bsz, c, h, wd = feat.shape
+        s = w1.shape[0]
+        k = (w2 if hid else w1).shape[1]
+        m = src.numel()
+        ctx.stacks = tuple(getattr(t, "_miseg_stack_params", None) for t in (w1, b1, w2, b2))
+        w1, b1 = w1.contiguous().float(), b1.contiguous().float()
+        w2, b2 = (w2.contiguous().float(), b2.contiguous().float()) if hid else (None, None)
+        pooled = torch.empty(m, c, dtype=torch.float32, device=feat.device)
+        prob = torch.empty(s, m, k, dtype=torch.float32, device=feat.device)
+        call("miseg_head_global_var_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), m, _ptr(w1), _ptr(b1), hid, _ptr(w2),
+             _ptr(b2), s, k, float(temperature), int(bool(normalize)), _ptr(pooled), _ptr(prob))
+        ctx.save_for_backward(w1, b1, w2, b2, src, pooled)
+        ctx.cfg = (float(temperature), bool(normalize), int(hid), k, bsz, c, h, wd, feat.dtype)
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        w1, b1, w2, b2, src, pooled = ctx.saved_tensors
+        temperature, normalize, hid, k, bsz, c, h, wd, dtype = ctx.cfg
+        s, m, dev = w1.shape[0], src.numel(), w1.device
+        gprob = gprob.contiguous().float()
+        gfeat = zeros_nhwc(bsz, c, h, wd, dtype, dev) if ctx.needs_input_grad[0] else None
+        gw1 = _stacked_grad(ctx.stacks[0], w1.shape, dev)
+        gb1 = _stacked_grad(ctx.stacks[1], b1.shape, dev)
+        gw2 = _stacked_grad(ctx.stacks[2], w2.shape, dev) if hid else None
+        gb2 = _stacked_grad(ctx.stacks[3], b2.shape, dev) if hid else None
+        dpool = torch.empty(s * m * c, dtype=torch.float32, device=dev)
+        call("miseg_head_global_var_bwd", _stream(), _DT[dtype], bsz, h, wd, c, _ptr(src), m, _ptr(w1), _ptr(b1), hid, _ptr(w2), _ptr(b2), s, k,
+             temperature, int(normalize), _ptr(pooled), _ptr(gprob), _ptr(gfeat), _ptr(gw1), _ptr(gb1), _ptr(gw2), _ptr(gb2), _ptr(dpool))
+        return gfeat, gw1, gb1, gw2, gb2, None, None, None, None
+
+
+def global_head_var(feat, w1, b1, w2, b2, src, temperature=1.0, normalize=False) -> Tensor:
+    hid = 0 if w2 is None else int(w1.shape[1])
+    if w2 is None:
+        w2 = b2 = torch.empty(0, device=feat.device)
+    return _GlobalHeadVar.apply(feat, w1, b1, w2, b2, src, float(temperature), bool(normalize), hid)
+
+
 # ------------------------------------------------------------------------------------------ pixel losses
 def _logits_nhwc(t: Tensor) -> Tensor:
     t = as_nhwc(t)
@@ -458,8 +582,10 @@ def softmax_kl(logits: Tensor, labels: Tensor, check_labels: bool = True) -> Ten
 
 
 class _SoftmaxMSE(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a: Tensor, b: Tensor, flips: Optional[Tensor]):
+    entry = "miseg_softmax_mse"
+
+    @classmethod
+    def forward(cls, ctx, a: Tensor, b: Tensor, flips: Optional[Tensor]):
         _need_gpu(a, b, flips)
         a, b = _logits_nhwc(a), _logits_nhwc(b.detach())
         n, c, h, w = a.shape
@@ -467,7 +593,7 @@ class _SoftmaxMSE(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ga = empty_nhwc(n, c, h, w, torch.float32, dev)
         ws = _ws(query("miseg_loss_ws_bytes", n, h, w), dev)
-        call("miseg_softmax_mse", _stream(), _ptr(a), _ptr(b), _ptr(flips), n, h, w, c, None, _ptr(loss), _ptr(ga), _ptr(ws), ws.numel())
+        call(cls.entry, _stream(), _ptr(a), _ptr(b), _ptr(flips), n, h, w, c, None, _ptr(loss), _ptr(ga), _ptr(ws), ws.numel())
         ctx.save_for_backward(ga)
         return loss
 
@@ -480,6 +606,15 @@ class _SoftmaxMSE(torch.autograd.Function):
 def softmax_mse(a: Tensor, b: Tensor, flips: Optional[Tensor] = None) -> Tensor:
     """mean((softmax(a) - softmax(flip(b)).detach())**2); ``flips`` replays the per-sample flip on b."""
     return _SoftmaxMSE.apply(a, b, flips)
+
+
+class _SoftmaxKLCons(_SoftmaxMSE):
+    entry = "miseg_softmax_klcons"
+
+
+def softmax_kl_consistency(a: Tensor, b: Tensor, flips: Optional[Tensor] = None) -> Tensor:
+    """KL_div()(softmax(a), softmax(flip(b)).detach()) -- the `UDARegCriterion.name: kl` consistency term, fused like softmax_mse."""
+    return _SoftmaxKLCons.apply(a, b, flips)
 
 
 def _flip_raw(x: Tensor, flips: Tensor) -> Tensor:

@@ -399,7 +399,9 @@ class UDATrainEpocher(TrainEpocher):
     def _uda(self, unlabeled_tf_logits: Tensor, unlabeled_logits: Tensor, flips: Tensor) -> Tensor:
         if isinstance(self._reg_criterion, nn.MSELoss):
             loss = LinearLoss.of(ops.softmax_mse(unlabeled_tf_logits, unlabeled_logits, flips))  # flip + 2 softmaxes + MSE fused
-        else:  # e.g. the KL variant (ref trainer.py:137): generic criterion on materialised operands
+        elif isinstance(self._reg_criterion, KL_div) and self._reg_criterion.supports_fused():   # `UDARegCriterion.name: kl`
+            loss = LinearLoss.of(ops.softmax_kl_consistency(unlabeled_tf_logits, unlabeled_logits, flips))
+        else:  # any other criterion object: called as the reference calls it, on materialised operands
             loss = self._reg_criterion(unlabeled_tf_logits.softmax(1), ops.flip(unlabeled_logits, flips).softmax(1).detach())
         self._pending.put("uda", loss)
         return loss

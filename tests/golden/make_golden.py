@@ -276,6 +276,11 @@ def gen_losses():
     mse = torch.nn.MSELoss()(a.softmax(1), b.softmax(1).detach())
     (ga,) = torch.autograd.grad(mse, [a])
     out.update({"mse/loss": mse, "mse/ga": ga})
+    # the `UDARegCriterion.name: kl` form of the consistency term (semi_seg/trainer.py:137,194 + epocher.py:221-224)
+    a2 = T(synth.normal("mse/a", (3, 4, 16, 16))).requires_grad_(True)
+    klc = KL_div(verbose=False)(a2.softmax(1), b.softmax(1).detach())
+    (ga2,) = torch.autograd.grad(klc, [a2])
+    out.update({"klc/loss": klc, "klc/ga": ga2})
     # simplex / one_hot truth table incl. the 1e-4 tolerance edge (general.py:176-196)
     base = torch.full((1, 4, 2, 2), 0.25)
     cases, sx, oh = [], [], []
@@ -465,11 +470,98 @@ def gen_step():
     save("step", **out)
 
 
+_tree = synth.tree_lines
+
+
+def gen_trainer_io():
+    """what the REFERENCE trainers write -- the checkpoint key tree (whl:trainer/_io.py:51-60: every attribute with
+    a state_dict + `_buffers`), the `storage.csv` header / index (whl:meters2/storage_interface.py:48-113) and the `config.yaml`
+    keys -- after two tiny CPU epochs of each of the four trainers, plus the key tree right after `init()`."""
+    import yaml
+    import tensorboardX
+
+    class _NoWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def __getattr__(self, k):      # scalar/figure adders only: the real writer has no state_dict, so neither may this one
+            if not k.startswith(("add_", "close", "flush")):
+                raise AttributeError(k)
+            return lambda *a, **kw: None
+
+    import deepclustering2.writer as ref_writer
+    import deepclustering2.trainer._trainer as ref_trainer_mod
+    ref_writer.SummaryWriter = ref_trainer_mod.SummaryWriter = tensorboardX.SummaryWriter = _NoWriter
+    from contrastyou.arch import UNet
+    from deepclustering2.loss import KL_div
+    from semi_seg.trainer import trainer_zoos
+    H, LB, UB = 32, 1, 1
+    out = {}
+
+    def train_loader(tag, B):
+        i = 0
+        while True:
+            img = T(synth.uniform(f"tio/{tag}{i}", (B, 1, H, H)))
+            tgt = T(synth.integers(f"tio/{tag}t{i}", (B, 1, H, H), 4))
+            yield [[[img, tgt], [img.clone(), tgt.clone()]], [f"patient{j:03d}_00_{j}" for j in range(B)], ["0"] * B,
+                   [f"patient{j:03d}_00" for j in range(B)]]
+            i += 1
+
+    class _Slices(torch.utils.data.Dataset):      # the reference's EvalEpocher insists on a real DataLoader (epocher.py:40)
+        def __init__(self, tag):
+            self._tag = tag
+
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            p, k = divmod(i, 2)
+            return [T(synth.uniform(f"tio/{self._tag}{i}", (1, H, H))), T(synth.integers(f"tio/{self._tag}t{i}", (1, H, H), 4))], \
+                f"patient{p:03d}_00_{k:02d}", "0", f"patient{p:03d}_00"
+
+    def EvalLoader(tag):
+        return torch.utils.data.DataLoader(_Slices(tag), batch_size=2, shuffle=False)
+
+    for name in ("partial", "uda", "iic", "udaiic"):
+        cfg = yaml.safe_load(open(os.path.join(REF, "config", "semi.yaml")))
+        cfg["Trainer"].update(name=name, device="cpu", max_epoch=2, num_batches=1, save_dir=f"golden_{name}")
+        cfg["Scheduler"]["warmup_max"] = 1
+        trainer_name = cfg["Trainer"].pop("name")
+        torch.manual_seed(0)
+        trainer = trainer_zoos[trainer_name](
+            model=UNet(**cfg["Arch"]), labeled_loader=train_loader("lab", LB), unlabeled_loader=train_loader("unl", UB),
+            val_loader=EvalLoader("val"), test_loader=EvalLoader("test"), sup_criterion=KL_div(verbose=False),
+            configuration={**cfg, "GITHASH": "none"}, **cfg["Trainer"])
+        trainer.init()
+        out[f"{name}/tree_after_init"] = np.asarray(sorted(_tree(trainer.state_dict())))
+        random.seed(7)
+        trainer.start_training()
+        run = trainer._save_dir
+        out[f"{name}/files"] = np.asarray(sorted(f for f in os.listdir(run) if not f.startswith("tensorboard")))
+        ck = torch.load(os.path.join(run, "last.pth"), map_location="cpu", weights_only=False)   # the file this very run wrote
+        out[f"{name}/tree_last_pth"] = np.asarray(sorted(_tree(ck)))
+        out[f"{name}/buffers"] = np.asarray([f"{k}={type(v).__name__}" for k, v in ck["_buffers"].items()])
+        with open(os.path.join(run, "storage.csv")) as f:
+            rows = f.read().splitlines()
+        out[f"{name}/csv_header"] = np.asarray(rows[0].split(","))
+        out[f"{name}/csv_index"] = np.asarray([r.split(",")[0] for r in rows[1:]])
+        saved_cfg = yaml.safe_load(open(os.path.join(run, "config.yaml")))
+        out[f"{name}/config_yaml_keys"] = np.asarray(sorted(f"{k}.{kk}" if isinstance(v, dict) else k for k, v in saved_cfg.items()
+                                                              for kk in (v if isinstance(v, dict) else [None])))
+    save("trainer_io", **out)
+
+
 def main():
     """``python make_golden.py [iic heads unet losses meters_sched step ...]`` -- no arguments = every fixture."""
     scratch = import_reference()
     gens = {"iic": gen_iic, "heads": gen_heads, "unet": gen_unet, "losses": gen_losses, "meters_sched": gen_meters_sched,
-            "step": gen_step}
+            "step": gen_step, "trainer_io": gen_trainer_io}
     try:
         torch.set_num_threads(8)
         for name in (sys.argv[1:] or list(gens)):

@@ -104,3 +104,26 @@ def fp_pack(prefix: str, fp: dict) -> dict:
 
 def fp_unpack(npz, prefix: str) -> dict:
     return {k: npz[f"{prefix}#{k}"] for k in ("shape", "sample", "sum", "abssum")}
+
+
+# ----------------------------------------------------------------------------- checkpoint key trees
+def tree_lines(obj, prefix: str = "") -> list:
+    """Flatten a nested checkpoint into 'path :: kind' lines: tensors as dtype + shape, other leaves as their Python type name.
+    Shared by make_golden.py (run on the reference's trainers) and the tests (run on this repo's)."""
+    import torch
+    lines = []
+    if isinstance(obj, dict):
+        if not obj:
+            lines.append(f"{prefix} :: empty-dict")
+        for k in obj:
+            lines += tree_lines(obj[k], f"{prefix}/{k}" if prefix else str(k))
+    elif isinstance(obj, (list, tuple)):
+        if not obj:
+            lines.append(f"{prefix} :: empty-{type(obj).__name__}")
+        for i, v in enumerate(obj):
+            lines += tree_lines(v, f"{prefix}[{i}]")
+    elif torch.is_tensor(obj):
+        lines.append(f"{prefix} :: tensor {str(obj.dtype).replace('torch.', '')} {list(obj.shape)}")
+    else:
+        lines.append(f"{prefix} :: {type(obj).__name__}")
+    return lines

@@ -57,3 +57,28 @@ def test_trainer_inference_dumps_pngs_and_reports_hausdorff(tmp_path):
     import numpy as np
     name = sorted(os.listdir(tmp_path / "run" / "pred"))[0]
     assert np.array(Image.open(tmp_path / "run" / "pred" / name)).max() <= 3
+
+
+@pytest.mark.parametrize("name", ["partial", "uda", "iic", "udaiic"])
+def test_run_directory_matches_the_reference_trainers(golden, tmp_path, name):
+    """SURVEY 8(f-3) after training: two tiny epochs of this repo's trainer write the files, the `last.pth` key tree (Adam state per
+    parameter, scheduler fields, `_storage` as pickled HistoricalContainer objects, `_buffers`), the `storage.csv` header / index
+    and the `config.yaml` keys the REFERENCE trainer of the same name wrote for the same configuration
+    (tests/golden/trainer_io.npz, make_golden.py::gen_trainer_io)."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import synth
+    from test_cpu_host import _build_trainer
+    g = golden("trainer_io")
+    tr = _build_trainer(name, tmp_path / "run", device="cuda")
+    tr.start_training()
+    run = tmp_path / "run"
+    assert sorted(f for f in os.listdir(run) if not f.startswith("tensorboard")) == [str(x) for x in g[f"{name}/files"]]
+    ck = torch.load(run / "last.pth", map_location="cpu", weights_only=False)
+    mine, ref = sorted(synth.tree_lines(ck)), [str(x) for x in g[f"{name}/tree_last_pth"]]
+    assert mine == ref, (sorted(set(mine) - set(ref))[:12], sorted(set(ref) - set(mine))[:12])
+    rows = open(run / "storage.csv").read().splitlines()
+    assert rows[0].split(",") == [str(x) for x in g[f"{name}/csv_header"]]
+    assert [r.split(",")[0] for r in rows[1:]] == [str(x) for x in g[f"{name}/csv_index"]]
+    assert [f"{k}={type(v).__name__}" for k, v in ck["_buffers"].items()] == [str(x) for x in g[f"{name}/buffers"]]

@@ -85,3 +85,23 @@ def test_adam_matches_oracle():
         hyper = torch.tensor([lr / (1 - b1 ** t), 1 / math.sqrt(1 - b2 ** t), eps, wd], dtype=torch.float32, device=DEV)
         unet_ops.adam_step(pd, gr.to(DEV), md, vd, hyper, b1, b2)
     np.testing.assert_allclose(pd.cpu().numpy(), ps[0].numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_softmax_kl_consistency_vs_golden_and_flip(golden):
+    """`UDARegCriterion.name: kl` (ref semi_seg/trainer.py:137,194): KL_div()(softmax(a), softmax(flip(b)).detach()) fused, against
+    the reference's own value / gradient (losses.npz klc/*) at 1e-5 relative, and with the flip replay against the oracle."""
+    g = golden("losses")
+    a = T(synth.normal("mse/a", (3, 4, 16, 16))).to(DEV).requires_grad_(True)
+    b = T(synth.normal("mse/b", (3, 4, 16, 16))).to(DEV)
+    loss = ops().softmax_kl_consistency(a, b, None)
+    np.testing.assert_allclose(float(loss), float(g["klc/loss"]), rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g["klc/ga"], rtol=1e-4, atol=1e-9)
+    dec = [[True, False], [False, True], [True, True]]
+    a2 = a.detach().clone().requires_grad_(True)
+    fused = ops().softmax_kl_consistency(a2, b, ops().flips_to_tensor(dec, DEV))
+    a_ref = a.detach().cpu().clone().requires_grad_(True)
+    ref = OL.kl_div(a_ref.softmax(1), OL.apply_flips(b.cpu(), dec).softmax(1))
+    np.testing.assert_allclose(float(fused), float(ref), rtol=1e-5)
+    fused.backward(), ref.backward()
+    np.testing.assert_allclose(a2.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4, atol=1e-9)
