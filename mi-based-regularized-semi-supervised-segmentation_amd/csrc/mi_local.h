@@ -73,4 +73,8 @@ int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_
                           const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
                           void* ws, int nterms);
 
+int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
+                          int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
+                          int accumulate, void* ws, int nterms);
+
 }  // namespace miseg

@@ -407,6 +407,10 @@ static int launch_bwd3(hipStream_t st, const float* x, const float* y, Bwd3Geom 
 int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
                           const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
                           void* ws, int nterms) {
+    // MISEG_BWD_KERNEL=tiles: the round-1 stacked-(b,o) + col2im kernel of this file; default: the row-streaming kernel
+    // (mi_local_bwd_rows.hip), same operands, same workspace size
+    static const bool tiles = [] { const char* e = getenv("MISEG_BWD_KERNEL"); return e && !strcmp(e, "tiles"); }();
+    if (!tiles) return launch_local_bwd_rows(st, x, y, S, hs, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, nterms);
     Bwd3Geom g{(int)N, (int)H, (int)W, (int)P, 256, accumulate, 8, (int)S, (long long)hs};
     if (P == 1) {   // one whole-image window (the shipped configuration): pick the segment length with the best block balance
         const int wb = 64 - 2 * (int)pad, tr = ((int)H + 3) / 4, tc = ((int)W + wb - 1) / wb;

@@ -48,8 +48,9 @@ def _adjacent(tensors) -> bool:
     if not t0.is_contiguous():
         return False
     step = t0.numel() * t0.element_size()
+    base = t0.untyped_storage().data_ptr()      # back to back in ONE storage (the flat buffer): separate allocations that merely happen to be neighbours do not count
     return all(t.shape == t0.shape and t.dtype == t0.dtype and t.is_contiguous() and t.data_ptr() == t0.data_ptr() + i * step
-               for i, t in enumerate(tensors))
+               and t.untyped_storage().data_ptr() == base for i, t in enumerate(tensors))
 
 
 def _stack_view(t0: Tensor, n: int) -> Tensor:
