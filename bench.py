@@ -112,8 +112,45 @@ def cpu_baseline(threads):
         OS.train_step(state, lab, tgt, unl, seed=123 + steps, mode="udaiic")
         steps += 1
     dt = time.time() - t0
-    return {"value": round(steps * (lb + ub) / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} udaiic train steps of the CPU oracle (oracle/step.py), LB=UB={lb}, 256x256, fp32, {dt:.1f} s after one warm-up step"}
+    out = {"value": round(steps * (lb + ub) / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": f"{steps} udaiic train steps of the CPU oracle (oracle/step.py), LB=UB={lb}, 256x256, fp32, {dt:.1f} s after one warm-up step"}
+    # the bench's own shape (BASELINE configs[1]: LB=UB=16), ONE step: ~10 s on 16 cores
+    big = 16
+    lab, tgt = torch.rand(big, 1, 256, 256, generator=g), torch.randint(0, 4, (big, 1, 256, 256), generator=g)
+    unl = torch.rand(big, 1, 256, 256, generator=g)
+    t0 = time.time()
+    OS.train_step(state, lab, tgt, unl, seed=999, mode="udaiic")
+    dt2 = time.time() - t0
+    out["cfg2_shape"] = {"value": round(2 * big / dt2, 4), "unit": "images/s", "sample": f"1 udaiic train step at LB=UB={big}, 256x256, fp32, {dt2:.1f} s"}
+    return out
+
+
+PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r02_pmc.json
+    "iic_local_bwd[p3]": "local_bwd_rows_kernel<20, 3, 3", "iic_local_bwd[p1]": "local_bwd_rows_kernel<20, 1, 3",
+    "iic_local_joint_fwd[p3]": "joint_fwd_bf16_kernel<9, 9, 3, 3>", "iic_local_joint_fwd[p1]": "joint_fwd_bf16_kernel<4, 4, 1, 3>",
+}
+
+
+def pmc_fields(tag, flops_per_call, lib_version, args, path=None):
+    """traffic (HBM bytes per launch, FETCH_SIZE + WRITE_SIZE), mfma_busy_frac (SQ_VALU_MFMA_BUSY_CYCLES / all SIMD cycles),
+    clock_ghz and ceiling_frac = algorithmic flop / flop of the MFMAs the kernel issues (SQ_INSTS_MFMA x flop per instruction): what
+    `frac` would read with the matrix pipe 100 % busy at the clock the peak is quoted for -- bf16x3 issues three MFMAs per
+    algorithmic product and tiles pad.  All null unless profiles/r02_pmc.json was taken on this library version and shape."""
+    none = {"traffic": None, "mfma_busy_frac": None, "ceiling_frac": None, "clock_ghz": None, "pmc_source": None}
+    try:
+        pmc = json.load(open(path or os.path.join(ROOT, "profiles", "r02_pmc.json")))
+    except (OSError, ValueError):
+        return none
+    if pmc.get("lib_version") != lib_version or not (args.lb == 16 and args.ub == 16 and args.size == 256 and args.dtype == "bfloat16"):
+        return none
+    prefix = PMC_KERNEL.get(tag)
+    hit = next((v for k, v in pmc.get("kernels", {}).items() if prefix and k.startswith(prefix)), None)
+    if hit is None:
+        return none
+    issued = hit.get("issued_mfma_flop")
+    return {"traffic": hit.get("traffic_bytes_factor1"), "mfma_busy_frac": hit.get("mfma_busy_frac"), "clock_ghz": hit.get("clock_ghz"),
+            "ceiling_frac": round(flops_per_call / issued, 4) if issued else None,
+            "pmc_source": f"profiles/r02_pmc.json (rocprofv3 --pmc, library version {lib_version}; bash profiles/collect_pmc.sh)"}
 
 
 def input_pipeline_bench(args):
@@ -381,13 +418,10 @@ def main():
                                "frac": round(tf / peak, 4), "traffic": None, "avg_ms": round(top["avg_ms"], 4), "calls_per_step": calls_per_step, "events_from": timed_in,
                                "mfma_dtype": "f32" if mfma_f32 else "bf16",
                                "hbm_achieved_GBps": round(top["bytes_per_call"] / (top["avg_ms"] * 1e-3) / 1e9, 1)}
-            try:   # HBM traffic of the same kernel/shape from the committed rocprofv3 PMC passes (not collectable in-process)
-                tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json"))).get(name)
-                if tr and args.lb == 16 and args.ub == 16 and args.size == 256:
-                    out["roofline"]["traffic"] = tr["traffic_bytes"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; calibration notes inside)"
-            except (OSError, ValueError):
-                pass
+            # Hardware counters of the same kernel / shape from the committed rocprofv3 PMC passes (profiles/collect_pmc.sh; counters
+            # cannot be collected in-process).  The file is keyed by kernel name AND library version: numbers taken on another build of
+            # the library are ignored (null), never quoted.
+            out["roofline"].update(pmc_fields(name, top["flops_per_call"], _cabi.lib().miseg_version(), args))
             out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:10]}
         if world == 1 and not args.no_cpu_baseline:
             try:

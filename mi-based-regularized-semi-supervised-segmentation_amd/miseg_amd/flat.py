@@ -178,14 +178,18 @@ class FusedAdam(torch.optim.Optimizer):
             t = self._steps[gi]
             b1, b2 = group["betas"]
             bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-            host = self._hyper_host[gi] if gi < len(self._hyper_host) else None
-            if host is None or host.device.type != "cpu":
-                host = torch.zeros(4, dtype=torch.float32)
+            # Pinned staging, FOUR slots used round-robin: the copy below is asynchronous and the training loop reads iteration i's
+            # scalars only after iteration i+1 is enqueued (semi_seg/epocher.py _after_step), so the host can be two steps ahead of
+            # the copy engine -- a single slot would be rewritten for step i+2 while step i+1's copy may still be queued.
+            while len(self._hyper_host) <= gi:
+                self._hyper_host.append(None)
+            ring = self._hyper_host[gi]
+            if ring is None or ring.device.type != "cpu":
+                ring = torch.zeros(4, 4, dtype=torch.float32)
                 if self._hyper[gi].is_cuda:
-                    host = host.pin_memory()
-                while len(self._hyper_host) <= gi:
-                    self._hyper_host.append(None)
-                self._hyper_host[gi] = host
+                    ring = ring.pin_memory()
+                self._hyper_host[gi] = ring
+            host = ring[t % 4]
             host[0], host[1], host[2], host[3] = group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]
             self._hyper[gi].copy_(host, non_blocking=True)
 

@@ -100,9 +100,15 @@ class LinearLoss:
         return evaluate([self])[0]
 
 
-def evaluate(items: Sequence[Union[LinearLoss, Tensor]]) -> Tensor:
-    """float32 device vector with the value of every item: one cat of the distinct base tensors, one mat-vec."""
+def evaluate(items: Sequence[Union[LinearLoss, Tensor]], passthrough: Sequence[Tensor] = ()) -> Tensor:
+    """float32 device vector with the value of every item (one cat of the distinct base tensors, one mat-vec), followed by the
+    0-d ``passthrough`` tensors verbatim.  The mat-vec multiplies EVERY base value into EVERY row (with coefficient 0 where a
+    row does not use it), and 0 * NaN = 0 * inf = NaN: one non-finite base value would poison all rows.  So the product runs on
+    a NaN/inf-free copy of the base vector and the rows that really use a non-finite value are set to NaN afterwards (a second
+    mat-vec with the 0/1 usage pattern); check flags travel as ``passthrough`` and never enter the product at all."""
     items = [LinearLoss.of(x) for x in items]
+    if not items:
+        return torch.stack([t.detach().reshape(()).float() for t in passthrough])
     base: Dict[int, Tuple[int, Tensor]] = {}
     offset = 0
     for it in items:
@@ -122,5 +128,11 @@ def evaluate(items: Sequence[Union[LinearLoss, Tensor]]) -> Tensor:
                 for t, c in it.terms:
                     o = base[id(t)][0]
                     m[r, o:o + t.numel()] += c
-            return m.to(dev)
-        return _const(key, build) @ flat
+            return m.to(dev), (m != 0).float().to(dev)
+        coeff, uses = _const(key, build)
+        bad = ~torch.isfinite(flat)
+        out = coeff @ torch.where(bad, torch.zeros_like(flat), flat)
+        out = torch.where((uses @ bad.float()) > 0, torch.full_like(out, float("nan")), out)
+        if passthrough:
+            out = torch.cat([out] + [t.detach().reshape(1).float() for t in passthrough])
+        return out

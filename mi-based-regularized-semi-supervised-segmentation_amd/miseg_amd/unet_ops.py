@@ -229,6 +229,10 @@ class _ConvBNReLU(torch.autograd.Function):
                 side = wgrad_stream(dev)      # only when the result lands in the flat buffer: nothing on this stream touches it again
             cur = torch.cuda.current_stream(dev)
             if side is not None:
+                if not _wgrad_dirty:          # first side-stream wgrad of this backward pass: join when the pass ends, so that
+                    # param.grad (which already aliases the flat slot) is safe to touch from the main stream as soon as
+                    # backward() returns -- gradient accumulation, clip_grad_norm_, inspection -- not only after collect()
+                    torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
                 side.wait_stream(cur)         # graw is produced above
                 for t in (graw, x0, x1):      # keep their memory from being recycled under the side stream
                     if t is not None:

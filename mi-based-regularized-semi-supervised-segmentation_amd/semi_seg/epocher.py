@@ -75,7 +75,7 @@ class _Pending:
 
     def device_values(self) -> Tensor:
         """float32 device vector: the put() values followed by the deferred-check flags (one cat + one mat-vec)."""
-        return lazy.evaluate(self._vals + [checks.flag_tensor(c) for c in self.checks])
+        return lazy.evaluate(self._vals, passthrough=[checks.flag_tensor(c) for c in self.checks])
 
     def fetch(self) -> dict:
         if self._static is not None:      # values of a replayed step graph: one static device tensor, fixed names and checks

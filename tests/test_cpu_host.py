@@ -359,3 +359,26 @@ def test_reference_layout_checkpoint_loads_strictly(golden, tmp_path):
     assert tr2._start_epoch == 2 and tr2._best_score == 0.25
     assert sorted(tr2._storage.meter_names) == sorted(hist) and tr2._storage.summary().shape[0] == 2
     assert tr2._optimizer._pending_state is not None or tr2._optimizer._steps[0] == 2     # applied now (GPU) or when the parameters reach the GPU
+
+
+def test_lazy_evaluate_isolates_non_finite_values_and_keeps_flags_out_of_the_product():
+    """One NaN / inf scalar must not turn every reported scalar (and every deferred-check flag) into NaN: 0 * NaN = NaN in the
+    coefficient mat-vec.  Rows that do not use the bad value keep their values; flags pass through untouched."""
+    from miseg_amd import lazy
+    a, b, c = torch.tensor([1.0, 2.0]), torch.tensor(float("nan")), torch.tensor(float("inf"))
+    la, lb, lc = lazy.LinearLoss.mean(a), lazy.LinearLoss.of(b) * 2.0, lazy.LinearLoss.of(c)
+    out = lazy.evaluate([la, lb, la + lb, lc, la * 3.0], passthrough=[torch.tensor(0.0), torch.tensor(3.0)])
+    assert out[0] == 1.5 and out[4] == 4.5
+    assert torch.isnan(out[1]) and torch.isnan(out[2]) and not torch.isfinite(out[3])
+    assert out[5] == 0.0 and out[6] == 3.0
+    # the epocher's container: a NaN loss raises ITS RuntimeError, not the first registered (passing) check
+    from miseg_amd import checks
+    from semi_seg.epocher import _Pending
+    pend = _Pending()
+    with checks.deferred(pend.checks):
+        checks.require_zero(torch.tensor(0.0), AssertionError, "simplex")
+        checks.raise_if_nan(torch.tensor([float("nan")]), "loss is nan")
+        pend.put("loss", lb)
+        pend.put("other", la)
+    with pytest.raises(RuntimeError, match="loss is nan"):
+        pend.fetch()
