@@ -157,12 +157,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
             const int ca = col0 - PAD + lane, cb = ca + 64;
             const unsigned va = (rok && lane < C::WS && ca >= w0w && ca < w1w) ? (unsigned)ca * 4u : OOB;
             const unsigned vb = (rok && lane < C::WS - 64 && cb >= w0w && cb < w1w) ? (unsigned)cb * 4u : OOB;
+            // per-lane byte offset of the column in voffset (out of range = dropped), the wave-uniform row / channel part in soffset:
+            // no vector add per load
             const unsigned rowoff = ((unsigned)(n * K) * (unsigned)plane + (unsigned)(rok ? hsr : 0) * (unsigned)g.W) * 4u;
 #pragma unroll
             for (int c = 0; c < K; ++c) {
                 const unsigned so = rowoff + (unsigned)c * (unsigned)plane * 4u;
-                pfa[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(va == OOB ? OOB : va + so), 0, 0));
-                if (TAIL) pfb[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(vb == OOB ? OOB : vb + so), 0, 0));
+                pfa[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)va, (int)so, 0));
+                if (TAIL) pfb[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vb, (int)so, 0));
             }
         };
         // registers -> bf16 hi (+ lo) planes of row buffer `buf`, pixel-major [pixel][CS]: 4 channels per ds_write_b64
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
             // array needs a compile-time index; nothing is written back) and store it if it belongs to this unit
             const int h = hsr - PAD;
             const bool keep = h >= r0;                     // h < r1 by construction of hs_last
-            const unsigned rowo = ((unsigned)(n * K) * (unsigned)plane + (unsigned)(keep ? h : 0) * (unsigned)g.W + (unsigned)col0) * 4u;
+            const unsigned rowo = ((unsigned)(n * K) * (unsigned)plane + (unsigned)(keep ? h : 0) * (unsigned)g.W + (unsigned)col0) * 4u;   // wave-uniform
             f32x4 done[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) done[nt] = zero4;
@@ -331,24 +333,26 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
 #undef MISEG_ROWS_CASE
                 default: break;
             }
-            auto put = [&](float v, unsigned off) {
-                if (ACC) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)off, 0, 0));
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)off, 0, 0);
+            // voffset: lane-dependent part (column, channel 4q + r of a main tile / validity), soffset: the wave-uniform row offset
+            auto put = [&](float v, unsigned voff, unsigned soff) {
+                if (ACC) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)voff, (int)soff, 0));
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)voff, (int)soff, 0);
             };
+            const unsigned qplane = (unsigned)(4 * q) * (unsigned)plane * 4u;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned vo = (keep && col0 + nt * 16 + l15 < w1w) ? rowo + (unsigned)(nt * 16 + l15) * 4u : OOB;
+                const unsigned vo = (keep && col0 + nt * 16 + l15 < w1w) ? qplane + (unsigned)(nt * 16 + l15) * 4u : OOB;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) put(sc * done[nt][r], vo == OOB ? OOB : vo + (unsigned)(4 * q + r) * (unsigned)plane * 4u);
+                for (int r = 0; r < 4; ++r) put(sc * done[nt][r], vo, rowo + (unsigned)r * (unsigned)plane * 4u);
             }
 #pragma unroll
             for (int t = 0; t < RT; ++t) {                 // the four remaining channels of that row: lane-row q of remainder tile t is slot 4t + q
                 const bool mine = t * 4 + q == jdone;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned vo = (keep && mine && col0 + nt * 16 + l15 < w1w) ? rowo + (unsigned)(nt * 16 + l15) * 4u : OOB;
+                    const unsigned vo = (keep && mine && col0 + nt * 16 + l15 < w1w) ? (unsigned)(nt * 16 + l15) * 4u : OOB;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) put(sc * rem[t][nt][r], vo == OOB ? OOB : vo + (unsigned)(16 + r) * (unsigned)plane * 4u);
+                    for (int r = 0; r < 4; ++r) put(sc * rem[t][nt][r], vo, rowo + (unsigned)(16 + r) * (unsigned)plane * 4u);
                 }
             }
             if (hsr < hs_last) {
