@@ -34,48 +34,6 @@ __device__ __forceinline__ void split_store(float v, unsigned short* hi, unsigne
 
 constexpr int kBT = 512;        // 8 waves = 2 quads, two waves per SIMD: each SIMD hosts one wave of each quad
 
-// The MT x NT tiles of D in row-major order, cut into four runs: wave `ROLE` of a quad owns one run (~MT*NT/4 accumulator
-// tiles = 84 registers at 9 x 9), so two waves fit a SIMD and one's LDS phases can hide under the other's MFMAs.
-template <int MT, int NT, int ROLE>
-struct QuadTiles {
-    static constexpr int PER = (MT * NT + 3) / 4;
-    static constexpr bool mine(int m, int n) { return (m * NT + n) / PER == ROLE; }
-    static constexpr bool row_used(int m) {
-        for (int n = 0; n < NT; ++n)
-            if (mine(m, n)) return true;
-        return false;
-    }
-    static constexpr bool col_used(int n) {
-        for (int m = 0; m < MT; ++m)
-            if (mine(m, n)) return true;
-        return false;
-    }
-    static constexpr int first_col() {
-        for (int n = 0; n < NT; ++n)
-            if (col_used(n)) return n;
-        return 0;
-    }
-    static constexpr int next_col(int n) {      // next used column after n, NT if none
-        for (int k = n + 1; k < NT; ++k)
-            if (col_used(k)) return k;
-        return NT;
-    }
-    static constexpr int nth_col(int j) {       // j-th used column, NT if there are fewer
-        int r = 0;
-        for (int k = 0; k < NT; ++k)
-            if (col_used(k)) {
-                if (r == j) return k;
-                ++r;
-            }
-        return NT;
-    }
-    static constexpr int col_rank(int n) {      // how many used columns precede n
-        int r = 0;
-        for (int k = 0; k < n; ++k) r += col_used(k) ? 1 : 0;
-        return r;
-    }
-};
-
 template <int PAD> constexpr int T_of() { return 2 * PAD + 1; }
 
 template <int MT, int NT, int PAD, int NTERMS, int ROLE>
@@ -372,6 +330,9 @@ bool joint_fwd_bf16_supported(const JointGeom& g) {
 
 int launch_joint_fwd_bf16(hipStream_t st, const float* x, const float* y, const float* mask, const JointGeom& g, const int32_t* win,
                           float* partials, int nterms) {
+    // MISEG_FWD_KERNEL=copies: this file's kernel (x-shifted copies in LDS); default: pixel-major operands (mi_local_fwd_px.hip)
+    static const bool copies = [] { const char* e = getenv("MISEG_FWD_KERNEL"); return e && !strcmp(e, "copies"); }();
+    if (!copies) return launch_joint_fwd_px(st, x, y, g, win, partials, nterms);
     const size_t ldsb = bf16_lds_bytes(g, nterms);
     dim3 grid(g.G, g.P * g.S), block(kBT);
 #define JB(MT, NT, PAD, NTERMS)                                                                                                  \
