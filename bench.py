@@ -127,7 +127,7 @@ def cpu_baseline(threads):
 
 PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r02_pmc.json
     "iic_local_bwd[p3]": "local_bwd_rows_kernel<20, 3, 3", "iic_local_bwd[p1]": "local_bwd_rows_kernel<20, 1, 3",
-    "iic_local_joint_fwd[p3]": "joint_fwd_bf16_kernel<9, 9, 3, 3>", "iic_local_joint_fwd[p1]": "joint_fwd_bf16_kernel<4, 4, 1, 3>",
+    "iic_local_joint_fwd[p3]": "joint_fwd_px_kernel<3, 3>", "iic_local_joint_fwd[p1]": "joint_fwd_px_kernel<1, 3>",
 }
 
 
@@ -288,7 +288,9 @@ def main():
     ap.add_argument("--lb", type=int, default=16)
     ap.add_argument("--ub", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"],
+                    help="storage / MFMA operand type of the U-Net and head kernels (float16 = BASELINE configs[4]'s arithmetic: IEEE half, "
+                         "static loss scale MISEG_LOSS_SCALE, default 2^14)")
     ap.add_argument("--mi-precision", default=None, choices=["fp32", "bf16x3", "bf16"],
                     help="local-MI contraction arithmetic (default: bf16x3 with --dtype bfloat16, fp32 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -322,7 +324,7 @@ def main():
     device = torch.device("cuda", local)
     from miseg_amd import _cabi, ddp, ops
     _cabi.lib()
-    mi_prec = args.mi_precision or ("bf16x3" if args.dtype == "bfloat16" else "fp32")
+    mi_prec = args.mi_precision or ("bf16x3" if args.dtype in ("bfloat16", "float16") else "fp32")
     ops.set_mi_precision(mi_prec)
     distributed = ddp.init_from_env("nccl")
 
@@ -390,7 +392,7 @@ def main():
             "metric": "images/sec (UNet+IIC fwd/bwd) ACDC 256^2", "value": round(images / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
+            "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype],
             "data": {"synthetic": "synthetic", "host": "synthetic, pinned host batches copied to the device every step (PCIe-inclusive)",
                      "acdc": "synthetic ACDC-format PNG set through the device input pipeline (224^2 crops)"}[args.data],
             "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "

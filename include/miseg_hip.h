@@ -16,8 +16,9 @@
  *   - Return value: 0 = ok, <0 = error (MISEG_E_*).  miseg_last_error() gives the message of
  *     the last failure on the calling thread.  Nothing throws.
  *   - `dt` selects the storage/operand type of U-Net activations and packed weights:
- *     MISEG_F32 (exact fp32, v_mfma_f32_16x16x4_f32) or MISEG_BF16 (bf16 operands,
- *     v_mfma_f32_16x16x32_bf16, fp32 accumulate).  Statistics, losses, probabilities,
+ *     MISEG_F32 (exact fp32, v_mfma_f32_16x16x4_f32), MISEG_BF16 (bf16 operands,
+ *     v_mfma_f32_16x16x32_bf16, fp32 accumulate) or MISEG_F16 (the same kernels on IEEE half: 3 more mantissa bits,
+ *     5-bit exponent -- activation gradients need the caller's loss scaling).  Statistics, losses, probabilities,
  *     gradients of parameters and the optimiser are always fp32.
  *   - U-Net activations are NHWC ("channels last"): element (n,h,w,c) at ((n*H+h)*W+w)*C+c.
  *     Probability maps handed to the local-MI kernels are NCHW fp32 (the reference layout).
@@ -37,6 +38,7 @@ extern "C" {
 
 #define MISEG_F32 0
 #define MISEG_BF16 1
+#define MISEG_F16 2 /* IEEE half storage / operands (v_mfma_*_f16), fp32 accumulate: the U-Net, BN and head entry points that take `dt` */
 
 #define MISEG_OK 0
 #define MISEG_E_INVALID (-1) /* bad argument (shape, dtype, null pointer, unsupported size) */
@@ -287,6 +289,10 @@ int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, i
  * ------------------------------------------------------------------------------------------ */
 int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     int64_t numel, float beta1, float beta2, const float* hyper);
+/* The same update on gradients that carry a static loss scale (the fp16 storage mode seeds backward with
+ * grad_scale so that activation gradients stay inside half's range): grad is read as grad / grad_scale. */
+int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                           int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale);
 
 /* ------------------------------------------------------------------------------------------
  * Device input pipeline   ref: semi_seg/augment.py:7-52 (ACDCStrongTransforms),

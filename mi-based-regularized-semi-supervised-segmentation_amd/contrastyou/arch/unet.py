@@ -20,7 +20,8 @@ from miseg_amd import unet_ops
 
 __all__ = ["UNet"]
 
-_DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+_DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
+           "float16": torch.float16, "fp16": torch.float16, "half": torch.float16}
 
 
 def _as_dtype(d) -> torch.dtype:

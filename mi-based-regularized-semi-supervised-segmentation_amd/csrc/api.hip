@@ -3,7 +3,7 @@
 
 #include "common.h"
 
-namespace miseg {
+namespace miseg_core {
 static thread_local char g_err[512] = "";
 char* last_error_buf() { return g_err; }
 int fail(int code, const char* fmt, ...) {
@@ -13,7 +13,7 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
-}  // namespace miseg
+}  // namespace miseg_core
 
-extern "C" int miseg_version(void) { return 200; }   // round 2 (profiles/r02_*.json are keyed by this)
+extern "C" int miseg_version(void) { return 201; }   // round 2 (profiles/r02_*.json are keyed by this)
 extern "C" const char* miseg_last_error(void) { return miseg::last_error_buf(); }

@@ -20,7 +20,7 @@ template <> struct VT<bf16> {
     static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
         const unsigned u[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32((unsigned short)(u[i] & 0xffffu)); f[2 * i + 1] = bf16_bits_to_f32((unsigned short)(u[i] >> 16)); }
     }
     static __device__ __forceinline__ Raw pack(const float* f) {
         unsigned u[4];
@@ -352,10 +352,11 @@ __global__ void cast_pad_kernel(const TI* __restrict__ in, TO* __restrict__ out,
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float b1, float b2, const float* __restrict__ hyper) {
+                                                   float* __restrict__ v, int64_t n, float b1, float b2, const float* __restrict__ hyper,
+                                                   float inv_scale) {
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2], wd = hyper[3];
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float gi = g[i] + wd * p[i];
+        float gi = g[i] * inv_scale + wd * p[i];
         float mi = m[i] * b1 + (1.f - b1) * gi;
         float vi = v[i] * b2 + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
@@ -394,6 +395,7 @@ extern "C" int miseg_bn_eval_coeffs(void* stream, int64_t C, const float* gamma,
 
 extern "C" int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C, const float* saved,
                                  void* y, void* pooled) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_fwd, stream, MISEG_BF16, raw, N, H, W, C, saved, y, pooled);
     MISEG_REQUIRE(raw && saved && y, "bn_relu_fwd: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     MISEG_REQUIRE(C % V == 0, "bn_relu_fwd: C must be a multiple of %d", V);
@@ -419,6 +421,7 @@ extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_
 extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
                                  int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
                                  float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd, stream, MISEG_BF16, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes);
     (void)y;   // kept in the signature; the ReLU mask and pool routing are recomputed from raw (see bn_dz_foreach)
     MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && graw && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
@@ -451,6 +454,7 @@ extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const vo
 }
 
 extern "C" int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out, int accumulate) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_sumpool2x2, stream, MISEG_BF16, in, N, H, W, C, out, accumulate);
     MISEG_REQUIRE(in && out && H % 2 == 0 && W % 2 == 0, "sumpool2x2: bad args");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     MISEG_REQUIRE(C % V == 0, "sumpool2x2: C must be a multiple of %d", V);
@@ -464,6 +468,7 @@ extern "C" int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N,
 }
 
 extern "C" int miseg_axpy(void* stream, int dt, const void* src, void* dst, int64_t numel) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_axpy, stream, MISEG_BF16, src, dst, numel);
     MISEG_REQUIRE(src && dst, "axpy: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     MISEG_REQUIRE(numel % V == 0, "axpy: numel must be a multiple of %d", V);
@@ -476,6 +481,7 @@ extern "C" int miseg_axpy(void* stream, int dt, const void* src, void* dst, int6
 }
 
 extern "C" int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64_t Cin, int dt_out, void* out, int64_t CP) {
+    MISEG_F16_DISPATCH_ON(dt_out, miseg_cast_pad, stream, in, npix, Cin, MISEG_BF16, out, CP);
     MISEG_REQUIRE(in && out && Cin > 0 && CP >= Cin, "cast_pad: bad args");
     hipStream_t st = as_stream(stream);
     const int nb = ew_blocks(npix * CP);
@@ -486,10 +492,16 @@ extern "C" int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64
     return MISEG_OK;
 }
 
-extern "C" int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
-                               float beta1, float beta2, const float* hyper) {
+extern "C" int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                                      float beta1, float beta2, const float* hyper, float grad_scale) {
     MISEG_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && numel > 0, "adam_step: bad args");
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(numel)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper);
+    MISEG_REQUIRE(grad_scale > 0.f && std::isfinite(grad_scale), "adam_step: grad_scale must be a positive finite number");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(numel)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2,
+                       hyper, 1.f / grad_scale);
     MISEG_LAUNCH_CHECK("adam_kernel");
     return MISEG_OK;
+}
+extern "C" int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                               float beta1, float beta2, const float* hyper) {
+    return miseg_adam_step_scaled(stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, 1.f);
 }

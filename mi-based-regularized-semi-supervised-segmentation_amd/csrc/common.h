@@ -8,13 +8,43 @@
 #include <stdlib.h>
 #include <algorithm>
 
+// ---- the fp16 build -------------------------------------------------------------------------------------------------------
+// bn / conv / heads / heads_var / mi_global are compiled TWICE: as written (16-bit storage type = bf16) and with
+// -DMISEG_F16_BUILD, where the same sources get IEEE half as their 16-bit type: `bf16` below becomes __half, the conversion helpers
+// and the MFMA builtins switch to their f16 forms, the namespace becomes miseg_f16 and every C entry point is renamed f16_miseg_*
+// (f16_rename.h, generated from the header by the Makefile).  The primary entry points forward dt == MISEG_F16 calls to those
+// (MISEG_F16_DISPATCH_ON).  The data movement (LDS tiles, ds_read_b64_tr_b16, packed 16-bit stores) is type-agnostic.
+#ifdef MISEG_F16_BUILD
+#include <hip/hip_fp16.h>
+#include "f16_rename.h"
+#endif
 #include "../../include/miseg_hip.h"
+#ifndef MISEG_F16_BUILD
+#include "f16_protos.h"
+#define MISEG_F16_DISPATCH_ON(var, fn, ...)          \
+    do {                                            \
+        if (var == MISEG_F16) return f16_##fn(__VA_ARGS__); \
+    } while (0)
+#else
+#define MISEG_F16_DISPATCH_ON(var, fn, ...) do { } while (0)
+#endif
 
-namespace miseg {
-
+namespace miseg_core {
 // ---- error plumbing (thread-local message, C return codes) -------------------------------
 char* last_error_buf();
 int fail(int code, const char* fmt, ...);
+}  // namespace miseg_core
+
+#ifdef MISEG_F16_BUILD
+#define miseg miseg_f16
+#define __bf16 _Float16
+#define __float2bfloat16 __float2half
+#define __bfloat162float __half2float
+#endif
+
+namespace miseg {
+using miseg_core::fail;
+using miseg_core::last_error_buf;
 
 #define MISEG_REQUIRE(cond, ...)                                  \
     do {                                                          \
@@ -31,7 +61,11 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- element types ------------------------------------------------------------------------
+#ifdef MISEG_F16_BUILD
+typedef __half bf16;            // the 16-bit storage / operand type of this build (the name stays: the sources are shared)
+#else
 typedef __hip_bfloat16 bf16;
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -42,11 +76,32 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
 
+#ifdef MISEG_F16_BUILD
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __half2float(__ushort_as_half(b)); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) { return __half_as_ushort(__float2half(v)); }
+// the bf16 MFMA builtins of the shared sources -> their f16 forms (same shapes, same rates; operands re-typed bit for bit)
+typedef _Float16 miseg_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 miseg_h4 __attribute__((ext_vector_type(4)));
+template <typename A, typename B> __device__ __forceinline__ f32x4 f16_mfma_16x16x32(A a, B b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(miseg_h8, a), __builtin_bit_cast(miseg_h8, b), c, 0, 0, 0);
+}
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <typename A, typename B> __device__ __forceinline__ f32x16_t f16_mfma_32x32x16(A a, B b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(miseg_h8, a), __builtin_bit_cast(miseg_h8, b), c, 0, 0, 0);
+}
+template <typename A, typename B> __device__ __forceinline__ f32x4 f16_mfma_16x16x16(A a, B b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(miseg_h4, a), __builtin_bit_cast(miseg_h4, b), c, 0, 0, 0);
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) ::miseg_f16::f16_mfma_16x16x32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) ::miseg_f16::f16_mfma_32x32x16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) ::miseg_f16::f16_mfma_16x16x16(a, b, c)
+#else
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
     bf16 h = __float2bfloat16(v);
     return *reinterpret_cast<unsigned short*>(&h);
 }
+#endif
 
 // ---- wave64 / block reductions --------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -898,6 +898,7 @@ using namespace miseg;
 
 extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, int64_t Cout, int64_t Cin, int kind, int64_t ci_begin,
                                           int64_t ci_count, void* packed) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_pack_conv3x3_weights, stream, MISEG_BF16, w, Cout, Cin, kind, ci_begin, ci_count, packed);
     MISEG_REQUIRE(w && packed && Cout > 0 && Cin > 0, "pack_conv3x3_weights: bad args");
     if (!kind) { ci_begin = 0; ci_count = Cin; }
     MISEG_REQUIRE(ci_begin >= 0 && ci_count > 0 && ci_begin + ci_count <= Cin, "pack_conv3x3_weights: bad channel slice");
@@ -913,6 +914,7 @@ extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, 
 }
 
 extern "C" int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void* jobs_dev, int64_t njobs, int64_t total_blocks) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_pack_conv3x3_weights_multi, stream, MISEG_BF16, jobs_dev, njobs, total_blocks);
     MISEG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_conv3x3_weights_multi: bad args");
     static_assert(sizeof(PackJob) == 40, "PackJob layout must match miseg_pack_job");
     if (dt == MISEG_F32)
@@ -940,6 +942,7 @@ static int generic_tile_h(int dt, int64_t H, int64_t W) {
 }
 
 extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_stats_parts, MISEG_BF16, Cin, N, H, W);
     if (conv_streams(dt, Cin, N, H, W)) return stream_blocks(N, H, W);
     const int tw = tile_w(W);
     return N * cdiv(H, generic_tile_h(dt, H, W)) * cdiv(W, tw);
@@ -947,6 +950,7 @@ extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int
 
 extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                                  int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats);
     MISEG_REQUIRE(in0 && packed_w && out, "conv3x3_fwd: null pointer");
     MISEG_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0, "conv3x3_fwd: bad shape");
     MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_fwd: second source missing");
@@ -1015,6 +1019,7 @@ extern "C" int64_t miseg_conv3x3_wgrad_ws_bytes(int64_t N, int64_t H, int64_t W,
 
 extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                                    int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_wgrad, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes);
     MISEG_REQUIRE(in0 && gout && gw && ws, "conv3x3_wgrad: null pointer");
     MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_wgrad: second source missing");
     const int64_t Cin = C0 + C1;
@@ -1052,6 +1057,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
 
 extern "C" int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t Cin, const float* w,
                                  const float* bias, int64_t Cout, float* out) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv1x1_fwd, stream, MISEG_BF16, in, N, H, W, Cin, w, bias, Cout, out);
     MISEG_REQUIRE(in && w && bias && out, "conv1x1_fwd: null pointer");
     MISEG_REQUIRE(Cin == 16, "conv1x1_fwd: Cin must be 16 (unet.py:84)");
     const int64_t npix = N * H * W;
@@ -1078,6 +1084,7 @@ extern "C" int64_t miseg_conv1x1_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, i
 
 extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, int64_t N, int64_t H, int64_t W, int64_t Cin,
                                  const float* w, int64_t Cout, void* gin, float* gw, float* gbias, void* ws, int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv1x1_bwd, stream, MISEG_BF16, in, gout, N, H, W, Cin, w, Cout, gin, gw, gbias, ws, ws_bytes);
     MISEG_REQUIRE(in && gout && w && gw && gbias && ws, "conv1x1_bwd: null pointer");
     MISEG_REQUIRE(Cin == 16, "conv1x1_bwd: Cin must be 16");
     MISEG_REQUIRE(ws_bytes >= miseg_conv1x1_bwd_ws_bytes(N, H, W, Cin, Cout), "conv1x1_bwd: workspace too small");

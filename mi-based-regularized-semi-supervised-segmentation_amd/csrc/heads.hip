@@ -965,6 +965,7 @@ static bool head_fwd_mfma_off() {
 extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
                                     int64_t K, float T, float* prob, float simplex_tol, int32_t* simplex_violations) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_head_local_fwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, b, S, K, T, prob, simplex_tol, simplex_violations);
     MISEG_REQUIRE(feat && src && w && b && prob, "head_local_fwd: null pointer");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && K > 0 && K <= 64 && M > 0 && S > 0 && H > 0 && W > 0, "head_local_fwd: need C%%4==0, K<=64");
     MISEG_REQUIRE(simplex_violations == nullptr || K <= 32, "head_local_fwd: the fused simplex check needs K <= 32");
@@ -1023,6 +1024,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
                                     float T, const float* prob, const float* gprob, void* gfeat, float* gw, float* gb, void* ws,
                                     int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes);
     MISEG_REQUIRE(feat && src && w && prob && gprob && gw && gb && ws, "head_local_bwd: null pointer");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 128 && K > 0 && K <= 64 && S * K <= 256 && M > 0, "head_local_bwd: need C%%4==0, C<=128, S*K<=256");
     MISEG_REQUIRE(ws_bytes >= miseg_head_local_bwd_ws_bytes(M, H, W, C, S, K), "head_local_bwd: workspace too small");

@@ -332,6 +332,7 @@ extern "C" int miseg_iic_global_bwd(void* stream, const float* x, const float* y
 extern "C" int miseg_head_global_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                      const int32_t* src, int64_t M, const float* w, const float* b, int64_t S, int64_t K, float T,
                                      float* pooled, float* prob) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_head_global_fwd, stream, MISEG_BF16, feat, B, H, W, C, src, M, w, b, S, K, T, pooled, prob);
     MISEG_REQUIRE(feat && src && w && b && pooled && prob, "head_global_fwd: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_fwd: bad shape (K<=64)");
     hipStream_t st = as_stream(stream);
@@ -348,6 +349,7 @@ extern "C" int miseg_head_global_fwd(void* stream, int dt, const void* feat, int
 extern "C" int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src, int64_t M,
                                      const float* w, int64_t S, int64_t K, float T, const float* pooled, const float* prob,
                                      const float* gprob, void* gfeat, float* gw, float* gb, float* dz_ws) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_head_global_bwd, stream, MISEG_BF16, B, H, W, C, src, M, w, S, K, T, pooled, prob, gprob, gfeat, gw, gb, dz_ws);
     MISEG_REQUIRE(src && w && pooled && prob && gprob && gw && gb && dz_ws, "head_global_bwd: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_bwd: bad shape");
     hipStream_t st = as_stream(stream);

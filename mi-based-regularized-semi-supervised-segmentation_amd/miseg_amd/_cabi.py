@@ -18,7 +18,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 HEADER = os.path.join(REPO_ROOT, "include", "miseg_hip.h")
 LIB_PATH = os.environ.get("MISEG_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libmiseg_hip.so")   # override: A/B runs of two builds
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 _CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "void": None}
 

@@ -146,6 +146,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper: List[Optional[Tensor]] = [None] * len(self.param_groups)
         self._hyper_host: List[Optional[Tensor]] = []
         self._pending_state: Optional[dict] = None
+        self.grad_scale = 1.0   # gradients arrive multiplied by this (static loss scale of the fp16 mode); divided out in the kernel
 
     @property
     def flat(self) -> FlatBuffers:
@@ -200,7 +201,7 @@ class FusedAdam(torch.optim.Optimizer):
             fb = self._flats[gi]
             b1, b2 = group["betas"]
             fb.collect()
-            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2)
+            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2, self.grad_scale)
         unet_ops.PACK_CACHE.invalidate()   # the fp32 masters changed: packed operand copies are stale
 
     @torch.no_grad()

@@ -12,9 +12,9 @@ import torch
 from torch import Tensor
 
 from . import _cabi
-from ._cabi import BF16, F32, call, query
+from ._cabi import BF16, F16, F32, call, query
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
 def _stream() -> int:
@@ -377,7 +377,7 @@ class _LocalHead(torch.autograd.Function):
         gfeat = None
         if ctx.needs_input_grad[0]:
             rng = ctx.src_range
-            if rng is not None and feat.dtype == torch.bfloat16 and k == 20 and s == 5 and c in (16, 32) and 0 <= rng[0] <= rng[1] <= bsz:
+            if rng is not None and feat.dtype in (torch.bfloat16, torch.float16) and k == 20 and s == 5 and c in (16, 32) and 0 <= rng[0] <= rng[1] <= bsz:
                 # the shipped kernels store (not accumulate) every pixel and channel of the rows in src = [start, stop): only the
                 # other rows need the zero fill (a third of the 100 MB at the bench shape, on the step's critical path)
                 gfeat = torch.empty((bsz, c, h, wd), dtype=feat.dtype, device=feat.device, memory_format=torch.channels_last)

@@ -47,8 +47,18 @@ def join_wgrad_streams() -> None:
     _wgrad_dirty.clear()
 
 
+def loss_scale_of(model) -> float:
+    """Static loss scale of a model: 1 unless its activations are stored as IEEE half, whose range (6e-8 .. 65504) does not hold the
+    per-pixel gradients of a mean over 48 x 256 x 256 positions (~3e-7).  ``MISEG_LOSS_SCALE`` overrides the default 2^14; the
+    fused Adam divides it back out (``miseg_adam_step_scaled``), so the update equals the unscaled one up to rounding."""
+    net = getattr(model, "module", model)
+    if getattr(net, "compute_dtype", None) != torch.float16:
+        return 1.0
+    return float(os.environ.get("MISEG_LOSS_SCALE", 16384.0))
+
+
 def vec_of(dtype) -> int:
-    return 8 if dtype == torch.bfloat16 else 4
+    return 8 if dtype in (torch.bfloat16, torch.float16) else 4
 
 
 def stem_input(image: Tensor, dtype) -> Tensor:
@@ -300,8 +310,10 @@ def conv1x1(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return _Conv1x1.apply(x, weight, bias)
 
 
-def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, hyper: Tensor, beta1: float, beta2: float) -> None:
-    """Fused Adam on flat fp32 buffers; ``hyper`` = device fp32[4] (lr/bc1, 1/sqrt(bc2), eps, weight_decay)."""
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, hyper: Tensor, beta1: float, beta2: float,
+              grad_scale: float = 1.0) -> None:
+    """Fused Adam on flat fp32 buffers; ``hyper`` = device fp32[4] (lr/bc1, 1/sqrt(bc2), eps, weight_decay); ``grad`` is read as
+    grad / grad_scale (the static loss scale of the fp16 mode)."""
     _need_gpu(param, grad, exp_avg, exp_avg_sq, hyper)
-    call("miseg_adam_step", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1), float(beta2),
-         _ptr(hyper))
+    call("miseg_adam_step_scaled", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1),
+         float(beta2), _ptr(hyper), float(grad_scale))

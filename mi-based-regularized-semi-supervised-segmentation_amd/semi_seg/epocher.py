@@ -38,7 +38,7 @@ from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterIn
 from deepclustering2.optim import get_lrs_from_optimizer
 from deepclustering2.type import T_loader, T_loss, T_optim
 from deepclustering2.utils import class2one_hot
-from miseg_amd import checks, lazy, ops
+from miseg_amd import checks, lazy, ops, unet_ops
 from miseg_amd.lazy import LinearLoss
 from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
 
@@ -316,7 +316,15 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         self._optimizer.zero_grad()
         if self._reducer is not None:
             self._reducer.prepare()
-        total_loss.backward()
+        scale = unet_ops.loss_scale_of(self._model)
+        if scale != 1.0:
+            # fp16 storage mode: seed backward with the static loss scale; the fused Adam reads the gradients as grad / scale
+            if not hasattr(self._optimizer, "grad_scale"):
+                raise RuntimeError("Arch.compute_dtype=float16 needs the fused Adam (Optim.name=Adam), which undoes the loss scale")
+            self._optimizer.grad_scale = scale
+            (total_loss * scale).backward()
+        else:
+            total_loss.backward()
         if self._reducer is not None:
             self._reducer.finish()
         if hasattr(self._optimizer, "apply"):

@@ -14,16 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "mi-based-regularized-semi-supervised-segmentation_amd")
 
 
-@pytest.mark.parametrize("name", ["partial", "uda", "iic", "udaiic"])
-def test_main_cli_runs_every_trainer(name):
-    save = f"pytest_cli_{name}"
+@pytest.mark.parametrize("name,dtype", [("partial", "bfloat16"), ("uda", "bfloat16"), ("iic", "bfloat16"), ("udaiic", "bfloat16"),
+                                        ("udaiic", "float16")])
+def test_main_cli_runs_every_trainer(name, dtype):
+    save = f"pytest_cli_{name}_{dtype}"
     run_dir = os.path.join(PKG, "semi_seg", "runs", save)
     shutil.rmtree(run_dir, ignore_errors=True)
     try:
         res = subprocess.run(
             [sys.executable, "semi_seg/main.py", f"Trainer.name={name}", f"Trainer.save_dir={save}", "Trainer.device=cuda",
              "Trainer.max_epoch=2", "Trainer.num_batches=3", "Data.size=64", "LabeledData.batch_size=2",
-             "UnlabeledData.batch_size=2", "Arch.compute_dtype=bfloat16"],
+             "UnlabeledData.batch_size=2", f"Arch.compute_dtype={dtype}"],
             cwd=PKG, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         files = set(os.listdir(run_dir))
