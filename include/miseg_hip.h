@@ -238,6 +238,17 @@ int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int
 int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
                       int ups1, int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out,
                       float* stats_partials);
+/* conv3x3_fwd + bn_finalize in ONE launch (training mode): the block that finishes last sums the partial rows and writes
+ * `saved` / the running statistics itself (same formulas as miseg_bn_finalize; the sums are combined in a different but fixed
+ * order).  sync_counter: one int32 in device memory, 0 on entry, 0 again when the kernel ends -- the caller may hand the same
+ * counter to launch after launch on one stream, not to two launches that can run concurrently.  Only for shapes whose partial
+ * matrix one block can sum quickly: ask miseg_conv3x3_bn_fwd_fusable first (0 -> use conv3x3_fwd + bn_finalize). */
+int64_t miseg_conv3x3_bn_fwd_fusable(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout);
+int miseg_conv3x3_bn_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
+                         int ups1, int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out,
+                         float* stats_partials, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* saved,
+                         int32_t* sync_counter);
 int64_t miseg_conv3x3_wgrad_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
 int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
                         int ups1, int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw_oihw,
@@ -265,6 +276,12 @@ int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_t C);
 int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool,
                       int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
                       int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes);
+/* the same with the statistics finished by the last reduce block (no separate finalize launch) when sync_counter != NULL and the
+ * layer is narrow enough; sync_counter as in miseg_conv3x3_bn_fwd.  sync_counter == NULL is miseg_bn_relu_bwd. */
+int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool,
+                           int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
+                           int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes,
+                           int32_t* sync_counter);
 /* backward of nearest x2 upsample: out[n,h,w,c] = sum of the 2x2 block of in (NHWC dt). */
 int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out,
                      int accumulate);

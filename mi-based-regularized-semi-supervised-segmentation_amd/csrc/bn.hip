@@ -202,10 +202,16 @@ __device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T
     }
 }
 
+struct BnBwdFinish {
+    unsigned int* counter;           // null: bn_bwd_finalize_kernel is launched separately
+    const float* gamma; float* coeffs; float* ggamma; float* gbeta;
+    float count; int training;
+};
+
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ raw, const T* __restrict__ gy,
                                                                  const T* __restrict__ gpool, int N, int H, int W, int C,
-                                                                 const float* __restrict__ saved, float* __restrict__ parts) {
+                                                                 const float* __restrict__ saved, float* __restrict__ parts, BnBwdFinish fin) {
     constexpr int V = VT<T>::V;
     extern __shared__ float sacc[];  // [256][2*V] transposed reduce
     const int CV = C / V;
@@ -247,8 +253,20 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
             float tot = 0.f;
             for (int q = 0; q < nparts; ++q) tot += spart[nparts == 1 ? (int)threadIdx.x : q * nout + (int)threadIdx.x];
             const int cvv = oo / (2 * V), j = oo % (2 * V);
-            parts[((size_t)blockIdx.x * 2 + (j >= V)) * C + cvv * V + (j % V)] = tot;
+            store_part(&parts[((size_t)blockIdx.x * 2 + (j >= V)) * C + cvv * V + (j % V)], tot);
         }
+    }
+    if (fin.counter && last_block_arrives(fin.counter, gridDim.x)) {      // the body of bn_bwd_finalize_kernel, by the last block
+        const float* sums = block_column_sums(parts, (int)gridDim.x, 2 * C, sacc);     // sacc: 256 * 2V >= 1024 + 2C floats (host-checked)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float s1 = sums[c], s2 = sums[C + c];
+            fin.gbeta[c] = s1;
+            fin.ggamma[c] = s2;
+            fin.coeffs[c] = fin.gamma[c] * saved[C + c];
+            fin.coeffs[C + c] = fin.training ? s1 / fin.count : 0.f;
+            fin.coeffs[2 * C + c] = fin.training ? s2 / fin.count : 0.f;
+        }
+        last_block_done(fin.counter);
     }
 }
 
@@ -366,6 +384,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 static inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 8192)); }
+static const int64_t kFinishFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
 static inline int red_blocks(int64_t npix, int CV) {
     (void)CV;
     static const int cap = [] { const char* e = getenv("MISEG_RED_BLOCKS"); return e ? atoi(e) : 512; }();
@@ -418,10 +437,11 @@ extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_
     return ((int64_t)red_blocks(N * H * W, 1) * 2 * C + 3 * C) * 4;
 }
 
-extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
-                                 int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
-                                 float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
-    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd, stream, MISEG_BF16, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes);
+extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
+                                      int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
+                                      float* ggamma, float* gbeta, void* ws, int64_t ws_bytes, int32_t* sync_counter) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_sync, stream, MISEG_BF16, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws,
+                          ws_bytes, sync_counter);
     (void)y;   // kept in the signature; the ReLU mask and pool routing are recomputed from raw (see bn_dz_foreach)
     MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && graw && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
@@ -431,18 +451,25 @@ extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const vo
     MISEG_REQUIRE(ws_bytes >= miseg_bn_bwd_ws_bytes(N, H, W, C), "bn_relu_bwd: workspace too small");
     hipStream_t st = as_stream(stream);
     const int64_t npix = N * H * W;
-    const int nb = red_blocks(npix, CV);
+    int nb = red_blocks(npix, CV);
+    if (sync_counter && C % 4 == 0 && C <= 256) nb = (int)std::max<int64_t>(1, std::min<int64_t>(nb, kFinishFloats / (2 * C)));   // wide layers are small
     float* parts = (float*)ws;
     float* coeffs = parts + (size_t)nb * 2 * C;
-    const size_t lb = (size_t)256 * 2 * V * 4;
-#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts)
+    // the last reduce block finishes the statistics itself when the caller lends a counter and the partial matrix is small enough for
+    // one block (common.h, "last block finishes"); its scratch is the reduce's own LDS, widened to 1024 + 2C floats if need be
+    const bool finish = sync_counter && C % 4 == 0 && C <= 256 && (int64_t)nb * 2 * C <= kFinishFloats;
+    const size_t lb = std::max<size_t>((size_t)256 * 2 * V * 4, finish ? (size_t)(1024 + 2 * C) * 4 : 0);
+    BnBwdFinish fin{finish ? reinterpret_cast<unsigned int*>(sync_counter) : nullptr, gamma, coeffs, ggamma, gbeta, (float)npix, training};
+#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts, fin)
     if (dt == MISEG_F32) { if (gpool) RED(float, true); else RED(float, false); }
     else if (dt == MISEG_BF16) { if (gpool) RED(bf16, true); else RED(bf16, false); }
     else return fail(MISEG_E_INVALID, "bn_relu_bwd: bad dtype");
 #undef RED
     MISEG_LAUNCH_CHECK("bn_relu_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta);
-    MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    if (!finish) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta);
+        MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    }
     // elementwise pass: many more blocks than the reduce (no partials to bound), same thread -> channel-vector mapping
     const int na = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((gpool ? npix / 4 : npix) * CV, 256), 8192));
 #define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw)
@@ -451,6 +478,12 @@ extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const vo
 #undef APP
     MISEG_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return MISEG_OK;
+}
+
+extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
+                                 int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
+                                 float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
+    return miseg_bn_relu_bwd_sync(stream, dt, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, nullptr);
 }
 
 extern "C" int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out, int accumulate) {

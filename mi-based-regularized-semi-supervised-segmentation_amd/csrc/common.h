@@ -129,6 +129,88 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     __syncthreads();
     return red[16];
 }
+// ---- "last block finishes" (one launch instead of a reduce kernel + a finalize kernel) -------------------------------------------
+// Every block of a grid writes one row of a [nparts][ncols] fp32 matrix of partial sums, then calls last_block_arrives(): exactly
+// one block -- the last to arrive -- gets true, after which every row is visible to it (agent-scope release by the writers, acquire
+// by the reader: the per-XCD L2s are written back / invalidated by the fences).  `counter` must be 0 at launch; the caller's last
+// block sets it back to 0 (last_block_done), so one counter serves launch after launch on a stream.
+__device__ __forceinline__ bool last_block_arrives(unsigned int* counter, unsigned int total_blocks) {
+    __shared__ int s_last;
+    __syncthreads();                 // the block's partial-sum stores happen-before thread 0's release
+    if (threadIdx.x == 0) {
+        // ONE release per block, and a release only: __threadfence() in every thread is a release + ACQUIRE per wave, and the acquire
+        // half (buffer_inv sc1) drops the XCD's L2 lines under the blocks that are still streaming -- measured +20 % on the whole step
+#ifndef MISEG_PARTS_WRITE_THROUGH
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total_blocks - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the other blocks' rows (their release -> our ticket -> this acquire)
+    return true;
+}
+// A partial-sum store of a launch that ends in last_block_arrives().  With MISEG_PARTS_WRITE_THROUGH the rows go through the L2 as
+// agent-scope relaxed atomic stores (sc1: written through) and the ticket needs no release fence (no buffer_wbl2 per block).
+__device__ __forceinline__ void store_part(float* p, float v) {
+#ifdef MISEG_PARTS_WRITE_THROUGH
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void last_block_done(unsigned int* counter) {
+    if (threadIdx.x == 0) *counter = 0u;
+}
+// Column sums of parts[nparts][ncols] (ncols % 4 == 0, ncols <= 1024) by ONE 256-thread block, into lds[1024 .. 1024 + ncols); lds
+// holds >= 1024 + ncols floats.  16-byte loads, 256 / (ncols / 4) row groups in flight, combined in a fixed order: deterministic.
+__device__ __forceinline__ float* block_column_sums(const float* __restrict__ parts, int nparts, int ncols, float* lds) {
+    const int tid = threadIdx.x, nc4 = ncols >> 2;
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    float* out = lds + 1024;
+    for (int c0 = 0; c0 < nc4; c0 += 256) {                    // one pass unless ncols > 1024
+        const int w = min(nc4 - c0, 256), G = 256 / w, grp = tid / w, c4 = c0 + tid - grp * w;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < G)
+            for (int q = grp; q < nparts; q += G) {
+                const float4 v = *reinterpret_cast<const float4*>(parts + (size_t)q * ncols + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        __syncthreads();
+        l4[tid] = acc;
+        __syncthreads();
+        if (tid < w) {
+            float4 s = l4[tid];
+            for (int g2 = 1; g2 < G; ++g2) { const float4 v = l4[g2 * w + tid]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            out[4 * (c0 + tid) + 0] = s.x; out[4 * (c0 + tid) + 1] = s.y; out[4 * (c0 + tid) + 2] = s.z; out[4 * (c0 + tid) + 3] = s.w;
+        }
+    }
+    __syncthreads();
+    return out;
+}
+
+// BatchNorm statistics -> coefficients by the last block of the producing convolution (conv.hip) -- the body of bn_finalize_kernel.
+struct BnFinish {
+    unsigned int* counter;           // null: the caller launches bn_finalize_kernel itself
+    const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt; float* saved;
+    float count, eps, momentum;
+};
+__device__ __forceinline__ void bn_finish_block(const float* __restrict__ parts, int nparts, int C, const BnFinish& f, float* lds) {
+    const float* sums = block_column_sums(parts, nparts, 2 * C, lds);      // [sum | sum of squares] per channel
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float mean = sums[c] / f.count;
+        const float var = fmaxf(sums[C + c] / f.count - mean * mean, 0.f);  // biased batch variance
+        const float invstd = rsqrtf(var + f.eps), sc = f.gamma[c] * invstd;
+        f.saved[c] = mean; f.saved[C + c] = invstd; f.saved[2 * C + c] = sc; f.saved[3 * C + c] = f.beta[c] - mean * sc;
+        if (f.rmean) {
+            const float unb = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+            f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mean;
+            f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * unb;
+            if (c == 0 && f.nbt) f.nbt[0] += 1;
+        }
+    }
+}
+
 __device__ __forceinline__ float block_min(float v, float* red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     v = wave_min(v);

@@ -57,7 +57,7 @@ __device__ __forceinline__ void zero_vec(T* dst) {
 // COT: output channels per block; TW: tile width (32 or 16).  grid = (N*tilesR*tilesC, ceil(Cout/COT)).
 template <typename T, int COT, int TW, int THT>
 __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
-                                                        T* __restrict__ out, float* __restrict__ stats) {
+                                                        T* __restrict__ out, float* __restrict__ stats, BnFinish fin) {
     typedef Mma<T> MM;
     constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, RW = THT / 4, MTW = RW * MTR;   // RW rows of the tile per wave
     constexpr int KP = MM::KP;                              // LDS stride of one pixel / one weight row (elements)
@@ -201,8 +201,12 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
         if (tid < COT && co0 + tid < Cout) {
             float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
             float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
-            stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
-            stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
+            store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
+            store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
+        }
+        if (fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {   // the tile memory is dead: scratch for the sums
+            bn_finish_block(stats, (int)gridDim.x, Cout, fin, reinterpret_cast<float*>(smem));
+            last_block_done(fin.counter);
         }
     }
 }
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 template <int COT, int TW, int NVEC, bool DUAL>
 __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ wpk, int Cout,
-                                                               bf16* __restrict__ out, float* __restrict__ stats, int ntiles) {
+                                                               bf16* __restrict__ out, float* __restrict__ stats, int ntiles, BnFinish fin) {
     typedef bf16 T;
     typedef Mma<T> MM;
     constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
@@ -400,8 +404,12 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             }
         __syncthreads();
         if (tid < COT && co0 + tid < Cout) {
-            stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
-            stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+            store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid]);
+            store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid]);
+        }
+        if (fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {
+            bn_finish_block(stats, (int)gridDim.x, Cout, fin, reinterpret_cast<float*>(smem));
+            last_block_done(fin.counter);
         }
     }
 }
@@ -948,9 +956,8 @@ extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int
     return N * cdiv(H, generic_tile_h(dt, H, W)) * cdiv(W, tw);
 }
 
-extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
-                                 int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats) {
-    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats);
+static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                            int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats, BnFinish fin) {
     MISEG_REQUIRE(in0 && packed_w && out, "conv3x3_fwd: null pointer");
     MISEG_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0, "conv3x3_fwd: bad shape");
     MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_fwd: second source missing");
@@ -968,7 +975,7 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
         size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);                                  \
         hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
         hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
-                           (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats);                                       \
+                           (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats, fin);                                  \
     }
 #define LAUNCH(TT, COT, TWW) { if (th == 8) LAUNCH_TH(TT, COT, TWW, 8) else LAUNCH_TH(TT, COT, TWW, 16) }
     if (conv_streams(dt, C0 + C1, N, H, W)) {
@@ -978,7 +985,7 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
         const unsigned g = (unsigned)stream_blocks(N, H, W);                                                               \
         hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
         hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, DU>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
-                           (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx);                           \
+                           (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx, fin);                      \
     }
 #define SLAUNCH_NV(COT)                                                                                                    \
     {                                                                                                                     \
@@ -1003,6 +1010,32 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
 #undef LAUNCH_TH
     MISEG_LAUNCH_CHECK("conv3x3_kernel");
     return MISEG_OK;
+}
+
+extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                 int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats);
+    return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, BnFinish{});
+}
+
+// The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.
+static const int64_t kBnFinishMaxFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
+
+extern "C" int64_t miseg_conv3x3_bn_fwd_fusable(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
+    const int64_t parts = miseg_conv3x3_stats_parts(dt == MISEG_F16 ? MISEG_BF16 : dt, Cin, N, H, W);
+    return Cout % 4 == 0 && Cout <= 256 && parts * 2 * Cout <= kBnFinishMaxFloats;
+}
+
+extern "C" int miseg_conv3x3_bn_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                    int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                    int64_t* nbt, float* saved, int32_t* sync_counter) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_bn_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, gamma, beta,
+                          eps, momentum, rmean, rvar, nbt, saved, sync_counter);
+    MISEG_REQUIRE(stats && gamma && beta && saved && sync_counter, "conv3x3_bn_fwd: null pointer");
+    MISEG_REQUIRE(miseg_conv3x3_bn_fwd_fusable(dt, C0 + C1, N, H, W, Cout), "conv3x3_bn_fwd: shape not fusable (ask miseg_conv3x3_bn_fwd_fusable)");
+    BnFinish fin{reinterpret_cast<unsigned int*>(sync_counter), gamma, beta, rmean, rvar, (long long*)nbt, saved, (float)(N * H * W), eps, momentum};
+    return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, fin);
 }
 
 static int wgrad_splits(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {

@@ -15,8 +15,8 @@
 //     on the N side with dy.  9 x 9 tiles for pad 3 (the same count as the (dx*K + i) stacking), written out in the old
 //     (dx*K + i, dy*K + j) order so joint_reduce_kernel is shared.
 //   * a block walks DOWN a 64-pixel strip: quad 0 (waves 0-3) takes image row r, quad 1 row r+1; both read one ring of Y rows
-//     (r - p .. r + 1 + p live, the next two being filled); the tiles of D are split over the four waves of a quad in row-major
-//     runs (QuadTiles, as before): two waves per SIMD, one of each quad.
+//     (r - p .. r + 1 + p live, the next two being filled); the tiles of D are split over the four waves of a quad in 2 x 2 blocks
+//     (BlockTiles below): two waves per SIMD, one of each quad.
 //   * the next row pair travels global -> registers during the MFMAs (4 channels of a pixel per lane, so the LDS store is one
 //     ds_write_b64 per plane) and is committed after them.
 #include "mi_local.h"
@@ -27,7 +27,33 @@ typedef __bf16 pbf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int pu32x2 __attribute__((ext_vector_type(2)));
 #define PX_LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
 
-constexpr int kPT = 512;   // 8 waves: quad = wave >> 2, role = wave & 3
+constexpr int kPT = 512;   // 8 waves: quad = wave >> 2, role = wave & 3 (quad 0) or 3 - (wave & 3) (quad 1)
+
+// The MT x NT tiles of D cut into 2 x 2 near-square blocks, one per role: a wave reads the A fragments of ~MT/2 tile rows and the B
+// fragments of ~NT/2 tile columns per k-step (row-major runs, QuadTiles: ~MT/4 + 1 rows but ALL NT columns -- a quarter more
+// LDS reads, and the reads are what bounds this kernel).  The blocks are unequal (25 / 20 / 20 / 16 tiles at 9 x 9); quad 1 deals
+// them to its waves in reverse order, so the two waves that share a SIMD carry 41 / 40 / 40 / 41 tiles together.
+template <int MT, int NT, int ROLE>
+struct BlockTiles {
+    static constexpr int RS = (MT + 1) / 2, CS = (NT + 1) / 2;
+    static constexpr bool mine(int m, int n) { return ((m >= RS ? 2 : 0) + (n >= CS ? 1 : 0)) == ROLE; }
+    static constexpr bool row_used(int m) { return (m >= RS) == ((ROLE & 2) != 0); }
+    static constexpr bool col_used(int n) { return (n >= CS) == ((ROLE & 1) != 0); }
+    static constexpr int nth_col(int j) {       // j-th used column, NT if there are fewer
+        int r = 0;
+        for (int k = 0; k < NT; ++k)
+            if (col_used(k)) {
+                if (r == j) return k;
+                ++r;
+            }
+        return NT;
+    }
+    static constexpr int col_rank(int n) {      // how many used columns precede n
+        int r = 0;
+        for (int k = 0; k < n; ++k) r += col_used(k) ? 1 : 0;
+        return r;
+    }
+};
 
 template <int PAD>
 struct PX {
@@ -35,8 +61,11 @@ struct PX {
     static constexpr int WT = 64, KS = WT / 32, XW = WT + 2 * PAD, XWP = (XW + 7) / 8 * 8, RING = 2 * PAD + 4;
     // a row is TWO pixel-major arrays: classes 0..15 (32 B per pixel) and classes 16..19 (8 B per pixel).  With 32 B per pixel and
     // the k <-> pixel map below, the 32 lanes ds_read_b64_tr_b16 serves per LDS cycle read 8 consecutive pixels = all 64 banks once.
+    // The 4-class array of Y is read with the source lane group pq selecting the RING ROW (displacement 4 t + pq): its row stride is
+    // padded by 64 B so that the four groups of a half-wave land in four different 64-byte bank windows (unpadded, 512 B apart, they
+    // collided 4-way: 39 % of this kernel's LDS cycles were bank conflicts, profiles/r02_pmc.json at library version 201).
     static constexpr int CM = 16, CR = 4;
-    static constexpr int YROWM = WT * CM, YROWR = WT * CR, XROWM = XWP * CM, XROWR = XWP * CR;          // bf16 elements per row buffer
+    static constexpr int YROWM = WT * CM, YROWR = WT * CR + 32, XROWM = XWP * CM, XROWR = XWP * CR;     // bf16 elements per row buffer
 };
 
 struct PxGeom {
@@ -50,7 +79,7 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
     typedef PX<PAD> C;
     constexpr int K = C::K, T = C::T, RT = C::RT, MT = C::MT, NT = C::MT, NP = NTERMS == 1 ? 1 : 2, WT = C::WT, RING = C::RING, KS = C::KS;
     constexpr int CM = C::CM, CR = C::CR;
-    typedef QuadTiles<MT, NT, ROLE> TS;
+    typedef BlockTiles<MT, NT, ROLE> TS;
     constexpr size_t ymPlane = (size_t)RING * C::YROWM, yrPlane = (size_t)RING * C::YROWR, xmPlane = (size_t)4 * C::XROWM, xrPlane = (size_t)4 * C::XROWR;
     unsigned short* Ym = reinterpret_cast<unsigned short*>(lds);                     // [NP][RING][WT][16]
     unsigned short* Yr = Ym + (size_t)NP * ymPlane;                                   // [NP][RING][WT][4]
@@ -279,7 +308,8 @@ template <int PAD, int NTERMS>
 __global__ __launch_bounds__(kPT, 1) void joint_fwd_px_kernel(const float* __restrict__ x, const float* __restrict__ y, PxGeom g,
                                                               const int32_t* __restrict__ win, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch ((wave & 4) ? 3 - (wave & 3) : (wave & 3)) {
         case 0: joint_px_body<PAD, NTERMS, 0>(x, y, g, win, partials, ldsb); break;
         case 1: joint_px_body<PAD, NTERMS, 1>(x, y, g, win, partials, ldsb); break;
         case 2: joint_px_body<PAD, NTERMS, 2>(x, y, g, win, partials, ldsb); break;

@@ -47,6 +47,33 @@ def join_wgrad_streams() -> None:
     _wgrad_dirty.clear()
 
 
+class _SyncCounters:
+    """int32 counters for the "last block finishes" launches (miseg_conv3x3_bn_fwd, miseg_bn_relu_bwd_sync): zero when a launch
+    starts, zero again when it ends.  One zero-filled array per device, handed out round-robin, so that launches which could overlap
+    (different streams) never share a counter.
+    OFF by default (``MISEG_BN_FINISH=1`` turns it on): it removes 44 of the step's ~300 launches, but the finishing block's serial
+    tail (ticket atomic -> cache invalidate -> dependent loads of the partial rows from memory -> coefficients) costs more than the
+    5 us finalize kernel plus its launch gap did: 8.54 ms/step (rows written through, no release fence) and 8.83 ms (release fence
+    per block) against 8.03-8.10 ms with the separate finalize launches, same box, same run."""
+    SLOTS = 256
+
+    def __init__(self):
+        self._pool, self._next = {}, 0
+        self.enabled = os.environ.get("MISEG_BN_FINISH", "0") == "1"
+
+    def take(self, device) -> Optional[Tensor]:
+        if not self.enabled:
+            return None
+        pool = self._pool.get(device)
+        if pool is None:
+            pool = self._pool[device] = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+        self._next = (self._next + 1) % self.SLOTS
+        return pool[self._next:self._next + 1]
+
+
+SYNC_COUNTERS = _SyncCounters()
+
+
 def loss_scale_of(model) -> float:
     """Static loss scale of a model: 1 unless its activations are stored as IEEE half, whose range (6e-8 .. 65504) does not hold the
     per-pixel gradients of a mean over 48 x 256 x 256 positions (~3e-7).  ``MISEG_LOSS_SCALE`` overrides the default 2^14; the
@@ -190,13 +217,19 @@ class _ConvBNReLU(torch.autograd.Function):
         else:
             parts, stats = 0, None
         es = x0.element_size()
-        call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
-             _ptr(stats), work=(18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout)),
-             tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
-        if training:
+        work = (18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout))
+        counter = SYNC_COUNTERS.take(dev) if training and query("miseg_conv3x3_bn_fwd_fusable", _DT[dtype], c0 + c1, n, h, w, cout) else None
+        if counter is not None:     # the conv's last block turns the partial sums into `saved` / the running statistics itself
+            call("miseg_conv3x3_bn_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
+                 _ptr(stats), _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved),
+                 _ptr(counter), work=work, tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
+        else:
+            call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
+                 _ptr(stats), work=work, tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
+        if training and counter is None:
             call("miseg_bn_finalize", _stream(), _ptr(stats), parts, cout, n * h * w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved))
-        else:
+        elif not training:
             call("miseg_bn_eval_coeffs", _stream(), cout, _ptr(gamma), _ptr(beta), BN_EPS, _ptr(running_mean), _ptr(running_var), _ptr(saved))
         y = empty_nhwc(n, cout, h, w, dtype, dev)
         pooled = empty_nhwc(n, cout, h // 2, w // 2, dtype, dev) if want_pool else None
@@ -226,8 +259,8 @@ class _ConvBNReLU(torch.autograd.Function):
         if gbeta is None:
             gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
-        call("miseg_bn_relu_bwd", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
-             int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(),
+        call("miseg_bn_relu_bwd_sync", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
+             int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(), _ptr(SYNC_COUNTERS.take(dev)),
              work=(0.0, float(raw.element_size()) * n * h * w * cout * 5.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
         gw = None
         if ctx.needs_input_grad[2]:

@@ -231,3 +231,37 @@ def test_unet_hooks_and_state_dict_keys():
     assert set(seen) == set(net.component_names)
     assert seen["Conv5"] is enc[0] and seen["Up_conv2"] is dec[-1] and seen["DeConv_1x1"] is logits
     assert seen["Up_conv3"].shape == (2, 32, 16, 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 256, 256, 16, 16), (16, 128, 128, 32, 32), (48, 16, 16, 256, 256), (6, 50, 46, 24, 32), (48, 64, 64, 64, 64)])
+def test_bn_statistics_finished_by_the_last_block_equal_the_separate_finalize(shape, dtype, monkeypatch):
+    """miseg_conv3x3_bn_fwd / miseg_bn_relu_bwd_sync (the block that arrives last sums the partial rows and writes the coefficients)
+    against the two-launch form (miseg_bn_finalize / bn_bwd_finalize_kernel): the partial sums are the same numbers, only their
+    summation order differs -> 1e-6 relative on every statistic and gradient; run twice to prove the counter resets itself.
+    The last shape is above the fusable limit on the forward side (separate finalize) and fused on the backward side."""
+    from miseg_amd import unet_ops
+    n, h, w, cin, cout = shape
+    x = nhwc(T(synth.normal(f"bnfin/{shape}/x", (n, cin, h, w))).to(DEV).to(dtype))
+    wt = T(synth.normal(f"bnfin/{shape}/w", (cout, cin, 3, 3), scale=(2.0 / (cin * 9)) ** 0.5)).to(DEV)
+    cot = T(synth.normal(f"bnfin/{shape}/cot", (n, cout, h, w))).to(DEV)
+
+    def run(enabled):
+        monkeypatch.setattr(unet_ops.SYNC_COUNTERS, "enabled", enabled)
+        bn = {k: v.to(DEV) for k, v in make_bn(cout, f"bnfin/{shape}/bn").items()}
+        xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        gd, bd = bn["weight"].clone().requires_grad_(True), bn["bias"].clone().requires_grad_(True)
+        y, _ = unet_ops.conv_bn_relu(xd, None, wd, gd, bd, bn["running_mean"], bn["running_var"], bn["nbt"], True, 0, 0, False)
+        (y.float() * cot).sum().backward()
+        return [t.detach().float().cpu() for t in (y, bn["running_mean"], bn["running_var"], gd.grad, bd.grad, xd.grad, wd.grad)] + [int(bn["nbt"])]
+
+    ref = run(False)
+    for _ in range(2):
+        got = run(True)
+        assert got[-1] == ref[-1] == 1
+        for a, b, name in zip(got[:-1], ref[:-1], ("y", "running_mean", "running_var", "ggamma", "gbeta", "gx", "gw")):
+            tol = 1e-6 if dtype == torch.float32 or name.startswith(("running", "gg", "gb")) else 1.6e-2   # 16-bit outputs: one ulp
+            err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+            assert err <= tol, (name, err)
+    if unet_ops.SYNC_COUNTERS._pool:
+        assert all(int(p.abs().sum()) == 0 for p in unet_ops.SYNC_COUNTERS._pool.values())      # every counter is back at zero
