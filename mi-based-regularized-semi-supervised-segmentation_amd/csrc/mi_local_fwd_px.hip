@@ -69,7 +69,7 @@ struct PX {
 };
 
 struct PxGeom {
-    int N, H, W, P, S, G, L;      // L: image rows per segment (even)
+    int N, H, W, P, S, G;
     long long hs;
 };
 
@@ -92,8 +92,13 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
     x += (size_t)shead * g.hs;
     y += (size_t)shead * g.hs;
     const int h0 = win[p * 4 + 0], h1 = win[p * 4 + 1], w0 = win[p * 4 + 2], w1 = win[p * 4 + 3];
-    const int tc = (w1 - w0 + WT - 1) / WT, ns = (h1 - h0 + g.L - 1) / g.L;
-    const int nSeg = g.N * tc * ns;
+    // Work of a slot = the row PAIRS of its N * tc column strips, in (image, strip, row) order; the G blocks of the slot take equal
+    // contiguous shares of that list (to within one pair), so a block walks down a strip for as long as its share lasts and warms the
+    // Y ring only where it starts or changes strip (2-3 times, not once per fixed-size segment) -- and no block has a segment more
+    // than the others (fixed 32-row segments dealt round-robin: 11 for some blocks, 10 for the rest = 9 % of the launch idle).
+    const int tc = (w1 - w0 + WT - 1) / WT, pps = (h1 - h0 + 1) / 2;
+    const long long totalPairs = (long long)g.N * tc * pps;
+    const int qlo = (int)(totalPairs * blockIdx.x / g.G), qhi = (int)(totalPairs * (blockIdx.x + 1) / g.G);
     const size_t plane = (size_t)g.H * g.W;
     const unsigned pl4 = (unsigned)(plane * 4), wb = (unsigned)g.W * 4u;
     constexpr unsigned OOB = 0xC0000000u;
@@ -107,42 +112,65 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
     // ---- global -> registers -> LDS.  Task t of a row pair: (row kind, channel quad c4 = 4 consecutive channels); a lane is a pixel
     // and loads its 4 channels from 4 planes (each load coalesced across the wave), so the pixel-major store is one 8-byte word per
     // plane.  Kinds: 0 / 1 = the two new Y rows, 2 / 3 = the two X rows (64 pixels from column col0 - PAD), 4 = the X rows' tails
-    // (lane = (row, c4, pixel 64 ..)).  Tasks are dealt round-robin to the 8 waves: 20 + 2 tasks -> 3 per wave at most.
+    // (lane = (c4, pixel 64 ..)).  Tasks are dealt round-robin to the 8 waves: 20 + 2 tasks -> 3 per wave at most.
+    // t = wave + 8 i never changes, so everything that depends on the task alone -- which array, which word of a row buffer, the
+    // channel offset -- is worked out ONCE here; a segment adds the column part, a row pair only `row * W`.  (Deriving all of it per
+    // row pair from t cost ~800 mostly scalar, branchy instructions per wave and pair: the matrix pipe sat idle for half the kernel.)
     constexpr int NTASK = 22, TPW = (NTASK + 7) / 8;
-    float pf[TPW][4];
-    struct RowSet { int n, col0, ya, yb, xa, xb; };      // image rows of the four row loads (ya, yb: Y; xa, xb: X), may be outside the window
-    auto task_addr = [&](const RowSet& rs, int t, unsigned& vo, unsigned& so) {
-        // the per-lane byte offset (OOB if the lane has nothing to load) and the scalar offset of channel c4*4; t < 10 reads y, else x
-        int kind, c4, row, col;
-        if (t < 20) { kind = t / 5; c4 = t % 5; }
-        else { kind = 4; c4 = 0; }
-        bool ok;
-        if (kind < 2) {
-            row = kind == 0 ? rs.ya : rs.yb; col = rs.col0 + lane;
-            ok = row >= h0 && row < h1 && col < w1;
-        } else if (kind < 4) {
-            row = kind == 2 ? rs.xa : rs.xb; col = rs.col0 - PAD + lane;
-            ok = row >= h0 && row < h1 && col >= w0 && col < w1;
-        } else {   // tails: task 20 -> row xa, task 21 -> row xb; lane = c4 * (2 PAD) + pixel
-            row = t == 20 ? rs.xa : rs.xb; c4 = lane / (2 * PAD); col = rs.col0 - PAD + 64 + lane % (2 * PAD);
-            ok = lane < 5 * 2 * PAD && row >= h0 && row < h1 && col >= w0 && col < w1;
-        }
-        vo = ok ? (unsigned)row * wb + (unsigned)col * 4u + (kind == 4 ? (unsigned)(c4 * 4) * pl4 : 0u) : OOB;
-        so = (unsigned)rs.n * (unsigned)K * pl4 + (kind == 4 ? 0u : (unsigned)(c4 * 4) * pl4);
-    };
+    float pfA[TPW][4], pfB[TPW][4];                  // two register sets: the loads of pair i + 2 fly while those of pair i + 1 are committed
+    bool act[TPW], isY[TPW], tail[TPW];                  // wave-uniform
+    int odd[TPW];                                        // second row of the pair (wave-uniform)
+    unsigned chan_so[TPW];                               // bytes: first channel of the task (scalar part of the load address)
+    unsigned chan_vo[TPW];                               // bytes: lane-dependent channel offset (tails only)
+    unsigned dst0[TPW], lo_off[TPW], rstride[TPW];       // LDS bytes: the lane's word in row buffer 0 of its array (hi plane), hi -> lo, buffer stride
+    bool lane_st[TPW];                                   // this lane has a word to store
+    const int tl_c4 = lane / (2 * PAD), tl_px = 64 + lane % (2 * PAD);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wv + 8 * i;
+        act[i] = t < NTASK;
+        tail[i] = t >= 20;
+        const int kind = t < 20 ? t / 5 : 4, c4u = t < 20 ? t % 5 : 0;
+        isY[i] = kind < 2;
+        odd[i] = t < 20 ? (kind & 1) : t - 20;
+        const int c4v = tail[i] ? tl_c4 : c4u, px = tail[i] ? tl_px : lane;
+        const bool mainArr = c4v < 4;
+        chan_so[i] = tail[i] ? 0u : (unsigned)(c4u * 4) * pl4;
+        chan_vo[i] = tail[i] ? (unsigned)(tl_c4 * 4) * pl4 : 0u;
+        const unsigned short* base = isY[i] ? (mainArr ? Ym : Yr) : (mainArr ? Xm : Xr);
+        dst0[i] = (unsigned)((base - reinterpret_cast<unsigned short*>(lds)) + (mainArr ? px * CM + c4v * 4 : px * CR)) * 2u;
+        lo_off[i] = (unsigned)(isY[i] ? (mainArr ? ymPlane : yrPlane) : (mainArr ? xmPlane : xrPlane)) * 2u;
+        rstride[i] = (unsigned)(isY[i] ? (mainArr ? C::YROWM : C::YROWR) : (mainArr ? C::XROWM : C::XROWR)) * 2u;
+        lane_st[i] = act[i] && (!tail[i] || lane < 5 * 2 * PAD);
+    }
     const unsigned tbytes = (unsigned)((size_t)g.N * K * plane * 4);
     // two descriptors, chosen by a wave-uniform branch: a descriptor picked through a per-task pointer made the compiler wrap every
     // load in a waterfall loop (readfirstlane / saveexec / branch per load)
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)tbytes, 0x00020000);
-    auto prefetch = [&](const RowSet& rs) {
+    unsigned loff[TPW], seg_so[TPW];                     // per segment: the lane's column (bytes, OOB if it has nothing to load); image + channel
+    auto seg_setup = [&](int n, int col0) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wv + 8 * i;                     // wave-uniform
-            unsigned vo = OOB, so = 0;
-            if (t < NTASK) task_addr(rs, t, vo, so);
-            so = (unsigned)__builtin_amdgcn_readfirstlane((int)so);      // wave-uniform by construction: say so (else: a waterfall loop per load)
-            if (t < 10) {
+            const int col = tail[i] ? col0 - PAD + tl_px : (isY[i] ? col0 + lane : col0 - PAD + lane);
+            const bool okc = lane_st[i] && col < w1 && (isY[i] || col >= w0);
+            loff[i] = okc ? (unsigned)col * 4u + chan_vo[i] : OOB;
+            seg_so[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)n * (unsigned)K * pl4 + chan_so[i]));
+        }
+    };
+    // rows ybase, ybase + 1 of Y and xbase, xbase + 1 of X (rows outside the window read zeros: OOB + anything stays out of range)
+    auto prefetch = [&](float (&pf)[TPW][4], int ybase, int xbase) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int row = __builtin_amdgcn_readfirstlane((isY[i] ? ybase : xbase) + odd[i]);
+            const unsigned radd = (row >= h0 && row < h1) ? (unsigned)row * wb : OOB;
+            const unsigned vo = act[i] ? loff[i] + radd : OOB;
+            const unsigned so = seg_so[i];
+#ifdef MISEG_PX_NOLOAD
+            for (int c = 0; c < 4; ++c) pf[i][c] = __uint_as_float(vo + so + c);
+            continue;
+#endif
+            if (isY[i]) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) pf[i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, (int)vo, (int)(so + (unsigned)c * pl4), 0));
             } else {
@@ -151,60 +179,49 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
             }
         }
     };
-    auto commit = [&](const RowSet& rs, int xpar) {
+    auto commit = [&](float (&pf)[TPW][4], int ybase, int xpar) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wv + 8 * i;
-            if (t >= NTASK) continue;                     // wave-uniform
-            unsigned short* dst;
-            size_t lo_plane;                              // distance to the lo plane of the array written
-            if (t < 20) {
-                const int c4 = t % 5, kind = t / 5;       // kinds 0 / 1: the Y rows, 2 / 3: the X rows
-                if (kind < 2) {
-                    const int sl = ((kind == 0 ? rs.ya : rs.yb) + 4 * RING) % RING;
-                    dst = c4 < 4 ? Ym + (size_t)sl * C::YROWM + (size_t)lane * CM + c4 * 4 : Yr + (size_t)sl * C::YROWR + (size_t)lane * CR;
-                    lo_plane = c4 < 4 ? ymPlane : yrPlane;
-                } else {
-                    const int xb = 2 * xpar + (kind - 2);
-                    dst = c4 < 4 ? Xm + (size_t)xb * C::XROWM + (size_t)lane * CM + c4 * 4 : Xr + (size_t)xb * C::XROWR + (size_t)lane * CR;
-                    lo_plane = c4 < 4 ? xmPlane : xrPlane;
-                }
-            } else {
-                const int c4 = lane / (2 * PAD), px = 64 + lane % (2 * PAD), xb = 2 * xpar + (t - 20);
-                dst = c4 < 4 ? Xm + (size_t)xb * C::XROWM + (size_t)px * CM + c4 * 4 : Xr + (size_t)xb * C::XROWR + (size_t)px * CR;
-                lo_plane = c4 < 4 ? xmPlane : xrPlane;
-                if (lane >= 5 * 2 * PAD) continue;        // divergent: only the tail lanes store
-            }
+            if (!act[i]) continue;                        // wave-uniform
+            const int buf = __builtin_amdgcn_readfirstlane(isY[i] ? (ybase + odd[i] + 4 * RING) % RING : 2 * xpar + odd[i]);
+            unsigned char* dst = lds + dst0[i] + (unsigned)buf * rstride[i];
             unsigned hi[4], lo[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 hi[c] = f32_to_bf16_bits(pf[i][c]);
                 lo[c] = f32_to_bf16_bits(pf[i][c] - bf16_bits_to_f32((unsigned short)hi[c]));
             }
-            *reinterpret_cast<pu32x2*>(dst) = pu32x2{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
-            if (NP == 2) *reinterpret_cast<pu32x2*>(dst + lo_plane) = pu32x2{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
+            if (lane_st[i]) {                             // divergent for the tails only
+                *reinterpret_cast<pu32x2*>(dst) = pu32x2{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
+                if (NP == 2) *reinterpret_cast<pu32x2*>(dst + lo_off[i]) = pu32x2{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
+            }
         }
     };
 
 #pragma unroll 1
-    for (int seg = blockIdx.x; seg < nSeg; seg += g.G) {
-        const int sg = seg % ns, ct = (seg / ns) % tc, n = seg / (ns * tc);
-        const int col0 = w0 + ct * WT, r0 = h0 + sg * g.L, r1 = min(h1, r0 + g.L);
+    for (int q0 = qlo; q0 < qhi;) {
+        const int strip = q0 / pps, pr = q0 - strip * pps, n = strip / tc, ct = strip - n * tc;
+        const int npairs = min(qhi - q0, pps - pr);
+        const int col0 = w0 + ct * WT, r0 = h0 + 2 * pr, r1 = min(h1, r0 + 2 * npairs);
+        q0 += npairs;
         // ---- warm the ring: Y rows r0 - PAD .. r0 + PAD + 1 and X rows r0, r0 + 1 through the same task machinery, two Y rows at a time
+        seg_setup(n, col0);
         __syncthreads();                                  // the previous segment's rows are consumed
-        for (int w2 = 0; w2 < PAD + 1; ++w2) {
-            RowSet rs{n, col0, r0 - PAD + 2 * w2, r0 - PAD + 2 * w2 + 1, r0, r0 + 1};
-            prefetch(rs);
-            commit(rs, 0);
+        static_assert((PAD + 1) % 2 == 0, "the ring is warmed two rounds at a time");
+        for (int w2 = 0; w2 < PAD + 1; w2 += 2) {         // both register sets in flight: half as many exposed round trips
+            prefetch(pfA, r0 - PAD + 2 * w2, r0);
+            prefetch(pfB, r0 - PAD + 2 * w2 + 2, r0);
+            commit(pfA, r0 - PAD + 2 * w2, 0);
+            commit(pfB, r0 - PAD + 2 * w2 + 2, 0);
         }
         __syncthreads();
-#pragma unroll 1
-        for (int r = r0; r < r1; r += 2) {
+        // One pair of image rows.  Its loads are for the pair AFTER next (global -> registers takes longer than one pair's MFMAs: with
+        // a single register set 0.16 of the launch's 0.64 ms was the commit waiting for its loads); it commits the next pair's rows,
+        // fetched one pair earlier into the other register set.
+        auto do_pair = [&](int r, float (&pfIssue)[TPW][4], float (&pfCommit)[TPW][4]) {
             const int xpar = ((r - r0) >> 1) & 1;
             const bool more = r + 2 < r1;
-            // rows of the NEXT pair: its two new Y rows and its X rows (zeros outside the window / segment tail)
-            RowSet nx{n, col0, r + 2 + PAD, r + 3 + PAD, r + 2, r + 3};
-            if (more) prefetch(nx);
+            if (r + 4 < r1) prefetch(pfIssue, r + 4 + PAD, r + 4);
             const int rx = r + quad;                      // this quad's image row; an odd tail row (rx >= r1) multiplies zeros only if ...
             const unsigned short* Xbm = Xm + (size_t)(2 * xpar + quad) * C::XROWM;
             const unsigned short* Xbr = Xr + (size_t)(2 * xpar + quad) * C::XROWR;
@@ -226,6 +243,9 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     auto tr2 = [&](const unsigned short* p0, int step_elems) {          // one fragment = two transpose reads (hf = 0, 1)
+#ifdef MISEG_PX_NOLDS
+                        { const short v = (short)(size_t)p0; const s16x8 f = {v, v, v, v, (short)step_elems, v, v, v}; return __builtin_bit_cast(pbf16x8_t, f); }
+#endif
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(PX_LDS_S16X4(p0));
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(PX_LDS_S16X4(p0 + step_elems));
                         const s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -241,7 +261,10 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
                             af[pl][mt] = mt < T ? tr2(Xbm + pl * xmPlane + lane_m + (ks * 32 + mt) * CM, 16 * CM)                       // dx = mt
                                                 : tr2(Xbr + pl * xrPlane + xar[mt >= T ? mt - T : 0] + ks * 32 * CR, 16 * CR);
                     }
-                    constexpr int BQ = 2;                  // B fragments one tile column ahead of the MFMAs
+#ifndef MISEG_PX_BQ
+#define MISEG_PX_BQ 2
+#endif
+                    constexpr int BQ = MISEG_PX_BQ;        // B fragments BQ - 1 tile columns ahead of the MFMAs
                     pbf16x8_t bq[BQ][NP];
                     auto load_b = [&](int nt, pbf16x8_t* dst) {
 #pragma unroll
@@ -249,16 +272,22 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
                             dst[pl] = nt < T ? tr2(Ym + pl * ymPlane + ybm[nt < T ? nt : 0] + ks * 32 * CM, 16 * CM)
                                              : tr2(Yr + pl * yrPlane + ybr[nt >= T ? nt - T : 0] + ks * 32 * CR, 16 * CR);
                     };
-                    if (TS::nth_col(0) < NT) load_b(TS::nth_col(0), bq[0]);
+#pragma unroll
+                    for (int j = 0; j < BQ - 1; ++j)
+                        if (TS::nth_col(j) < NT) load_b(TS::nth_col(j), bq[j]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         if (!TS::col_used(nt)) continue;
                         const int rank = TS::col_rank(nt), sl = rank % BQ;          // compile-time after unrolling
-                        if (TS::nth_col(rank + 1) < NT) load_b(TS::nth_col(rank + 1), bq[(rank + 1) % BQ]);
+                        if (TS::nth_col(rank + BQ - 1) < NT) load_b(TS::nth_col(rank + BQ - 1), bq[(rank + BQ - 1) % BQ]);
                         __builtin_amdgcn_sched_barrier(0);    // keep the read-ahead where it is
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             if (!TS::mine(mt, nt)) continue;
+#ifdef MISEG_PX_NOMFMA
+                            acc[mt][nt][0] += (float)af[0][mt][0] * (float)bq[sl][0][0] + (float)af[NP - 1][mt][1] * (float)bq[sl][NP - 1][1];
+                            continue;
+#endif
                             if (NTERMS == 3) {
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1][mt], bq[sl][0], acc[mt][nt], 0, 0, 0);
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][mt], bq[sl][NP - 1], acc[mt][nt], 0, 0, 0);
@@ -268,8 +297,14 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
                     }
                 }
             }
-            if (more) commit(nx, xpar ^ 1);
+            if (more) commit(pfCommit, r + 2 + PAD, xpar ^ 1);
             __syncthreads();                              // next pair's rows visible; this pair's X buffers / oldest ring rows reusable
+        };
+        if (r0 + 2 < r1) prefetch(pfB, r0 + 2 + PAD, r0 + 2);
+#pragma unroll 1
+        for (int r = r0; r < r1; r += 4) {
+            do_pair(r, pfA, pfB);
+            if (r + 2 < r1) do_pair(r + 2, pfB, pfA);
         }
     }
     // ---- the two quads' accumulators meet in LDS (fixed order), in the (dx*K + i, dy*K + j) layout joint_reduce_kernel reads
@@ -326,8 +361,7 @@ static size_t px_lds(int nterms) {
 }
 
 int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& jg, const int32_t* win, float* partials, int nterms) {
-    PxGeom g{jg.N, jg.H, jg.W, jg.P, jg.S, jg.G, 32, jg.hs};
-    { const char* e = getenv("MISEG_FWD_PX_L"); if (e && atoi(e) > 0) g.L = atoi(e) & ~1; }
+    PxGeom g{jg.N, jg.H, jg.W, jg.P, jg.S, jg.G, jg.hs};
     dim3 grid(g.G, g.P * g.S), block(kPT);
 #define PXL(PADV, NT_)                                                                                                           \
     {                                                                                                                            \
