@@ -424,7 +424,7 @@ def main():
             # cannot be collected in-process).  The file is keyed by kernel name AND library version: numbers taken on another build of
             # the library are ignored (null), never quoted.
             out["roofline"].update(pmc_fields(name, top["flops_per_call"], _cabi.lib().miseg_version(), args))
-            out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:10]}
+            out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:int(os.environ.get("MISEG_BENCH_TOP", "10"))]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cores = len(os.sched_getaffinity(0))

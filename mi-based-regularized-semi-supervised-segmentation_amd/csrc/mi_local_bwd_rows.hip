@@ -50,7 +50,7 @@ struct R3 {
 };
 
 struct RowsGeom {
-    int N, H, W, P, S, L, accumulate, G;
+    int N, H, W, P, S, accumulate, G;
     long long hs;
 };
 
@@ -102,52 +102,62 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
     const unsigned tbytes = (unsigned)((size_t)g.N * K * plane * 4);
     constexpr unsigned OOB = 0xC0000000u;
 
-    // ---- units: (sdp = (sub-head, window, direction)) x (sample, column strip, run of <= L output rows); a block takes 4 at a time
-    // (one per wave), always of one sdp, so that the A image in LDS serves all four
-    int64_t per_head = 0;                                 // quads of one (s, dir): sum over windows, each padded to a multiple of 4 units
+    // ---- work = output rows.  All output rows of the launch in (direction, sub-head, window, sample, column strip, row) order form
+    // one list; the G blocks take equal contiguous shares of it and, inside a block, the waves equal contiguous shares of the part of
+    // the block's share that lies in one sdp = (sub-head, window, direction) -- the A image in LDS is per sdp, so a block changes it
+    // at most once or twice, all waves together.  A wave walks down a strip for as long as its share lasts (a "unit": rows [r0, r1) of
+    // one strip; it pays the 2 PAD warm-up source rows where it starts or changes strip).  Fixed 128-row units dealt round-robin
+    // left 512 of the 3072 waves -- 36 whole CUs -- without work at the cfg2 shape.
+    int64_t rows_head = 0;                                // output rows of one (direction, sub-head): sum over windows of N * strips * rows
     for (int p = 0; p < g.P; ++p) {
         const int tr = win[p * 4 + 1] - win[p * 4 + 0], tc = (win[p * 4 + 3] - win[p * 4 + 2] + C::WT - 1) / C::WT;
-        per_head += ((int64_t)g.N * tc * ((tr + g.L - 1) / g.L) + WAVES - 1) / WAVES;
+        rows_head += (int64_t)g.N * tc * tr;
     }
-    const int64_t nquads = per_head * g.S * 2;
-    int cur_sdp = -1;
+    const int64_t total_rows = rows_head * g.S * 2;
+    const int64_t blk_lo = total_rows * blockIdx.x / g.G, blk_hi = total_rows * (blockIdx.x + 1) / g.G;
 #pragma unroll 1
-    for (int64_t quad = blockIdx.x; quad < nquads; quad += g.G) {
-        // decode: quad -> (dir, s, p, first unit)
-        int64_t left = quad;
-        const int dir = (int)(left / (per_head * g.S));
-        left -= (int64_t)dir * per_head * g.S;
-        const int s = (int)(left / per_head);
-        left -= (int64_t)s * per_head;
-        int p = 0, tr = 0, tc = 0, ns = 0;
+    for (int64_t cur = blk_lo; cur < blk_hi;) {
+        // decode: cur -> (dir, s, p, row index inside the window's list)
+        int64_t left = cur;
+        const int dir = (int)(left / (rows_head * g.S));
+        left -= (int64_t)dir * rows_head * g.S;
+        const int s = (int)(left / rows_head);
+        left -= (int64_t)s * rows_head;
+        int p = 0, tr = 0, tc = 0;
+        int64_t rp = 0;
         for (; p < g.P; ++p) {
             tr = win[p * 4 + 1] - win[p * 4 + 0];
             tc = (win[p * 4 + 3] - win[p * 4 + 2] + C::WT - 1) / C::WT;
-            ns = (tr + g.L - 1) / g.L;
-            const int64_t qn = ((int64_t)g.N * tc * ns + WAVES - 1) / WAVES;
-            if (left < qn) break;
-            left -= qn;
+            rp = (int64_t)g.N * tc * tr;
+            if (left < rp) break;
+            left -= rp;
         }
+        const int64_t phase = min(blk_hi - cur, rp - left);                 // rows of this block's share inside (dir, s, p)
+        cur += phase;
         const int h0w = win[p * 4 + 0], h1w = win[p * 4 + 1], w0w = win[p * 4 + 2], w1w = win[p * 4 + 3];
         const int sdp = ((s * g.P + p) * 2 + dir);
-        if (sdp != cur_sdp) {                            // block-uniform
+        {                                                // block-uniform: every phase is a different sdp
             __syncthreads();                             // every wave is done with the previous A image
             const unsigned short* src = gpack + (size_t)sdp * KS * ASLICE;
             for (int idx = tid; idx < KS * ASLICE / 8; idx += 64 * WAVES)
                 *reinterpret_cast<ru32x4*>(Asm + (size_t)idx * 8) = *reinterpret_cast<const ru32x4*>(src + (size_t)idx * 8);
             __syncthreads();
-            cur_sdp = sdp;
         }
-        const int64_t unit = left * WAVES + wv;
-        if (unit >= (int64_t)g.N * tc * ns) continue;    // ragged last quad of a window: this wave idles (no barrier inside the unit)
-        const int sgi = (int)(unit % ns), ct = (int)((unit / ns) % tc), n = (int)(unit / ((int64_t)ns * tc));
-        const int col0 = w0w + ct * C::WT;
-        const int r0 = h0w + sgi * g.L, r1 = min(h1w, r0 + g.L);          // output rows of this unit
         const float* srcp = (dir ? x : y) + (size_t)s * g.hs;
         float* dstp = (dir ? gy : gx) + (size_t)s * g.hs;
         const float sc = scale[s * g.P + p];
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, (int)tbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)dstp, 0, (int)tbytes, 0x00020000);
+        int64_t wa = left + phase * wv / WAVES;
+        const int64_t wb = left + phase * (wv + 1) / WAVES;
+#pragma unroll 1
+      while (wa < wb) {                                  // units of this wave (no barrier inside)
+        const int strip = (int)(wa / tr), rr = (int)(wa - (int64_t)strip * tr);
+        const int len = (int)min((int64_t)(tr - rr), wb - wa);
+        wa += len;
+        const int n = strip / tc, ct = strip - n * tc;
+        const int col0 = w0w + ct * C::WT;
+        const int r0 = h0w + rr, r1 = r0 + len;          // output rows of this unit
 
         // ---- source row hs -> registers: lane = pixel col0 - PAD + lane (+ 64 for the 2 PAD tail pixels), 20 channel planes
         constexpr bool TAIL = C::WS > 64;                  // a 64-column strip needs 2 PAD more pixels than a wave has lanes
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
                 commit_row(NBUF == 2 ? buf ^ 1 : 0);
             }
         }
+      }
     }
 }
 
@@ -393,30 +404,14 @@ static int launch_rows(hipStream_t st, const float* x, const float* y, RowsGeom 
     return 0;
 }
 
-// Segment length L (output rows per unit): a unit streams L + 2 pad source rows, and the busiest wave sets the kernel's time.  The
-// window list lives on the device; for the one-window call (the shipped configuration: the whole map) the cost model below assumes
-// H x W, patch lists (P > 1) use 64-row segments.  L only moves work between waves -- any value is correct.
 int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                           int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
                           int accumulate, void* ws, int nterms) {
-    RowsGeom g{(int)N, (int)H, (int)W, (int)P, (int)S, 64, accumulate, 256, (long long)hs};
+    RowsGeom g{(int)N, (int)H, (int)W, (int)P, (int)S, accumulate, 256, (long long)hs};
     // Shape of a block = waves x strip width.  Measured on the cfg2 launch (S=5, N=16, 256^2, pad 3; bench, same box): 12x32 1.14 ms,
     // 8x32 1.17, 8x64 1.19, 4x64 1.31-1.38 (one wave per SIMD: nothing covers a wave's row-end fetch / split / store phase); the
     // stacked-(b,o) kernel 1.6.  12x32 = three waves per SIMD, no in-wave prefetch, 155 registers.  MISEG_BWD_ROWS_SHAPE selects.
     static const int wide = [] { const char* e = getenv("MISEG_BWD_ROWS_SHAPE"); return !e ? 3 : !strcmp(e, "4x64") ? 1 : !strcmp(e, "8x32") ? 0 : !strcmp(e, "8x64") ? 2 : !strcmp(e, "16x32") ? 4 : 3; }();
-    const int wt = (wide == 1 || wide == 2) ? 64 : 32, waves = wide == 1 ? 4 : wide == 3 ? 12 : wide == 4 ? 16 : 8;
-    if (P == 1) {
-        const int tcs = ((int)W + wt - 1) / wt;
-        double best = 1e30;
-        for (int L = 8; ; L *= 2) {
-            const int Lc = std::min(L, (int)H);
-            const int64_t units = 2 * S * N * (int64_t)tcs * (((int)H + Lc - 1) / Lc);
-            const double cost = (double)((units + waves * g.G - 1) / (waves * g.G)) * (Lc + 2.0 * pad);
-            if (cost < best - 1e-9) { best = cost; g.L = Lc; }
-            if (L >= (int)H) break;
-        }
-    }
-    { const char* e = getenv("MISEG_BWD_ROWS_L"); if (e && atoi(e) > 0) g.L = atoi(e); }
     if (wide == 1) {
         if (pad == 3) return launch_rows<20, 3, 4, 4>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
         return launch_rows<20, 1, 4, 4>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
