@@ -31,6 +31,9 @@ import torch  # noqa: E402
 
 FEATURES = ["Conv5", "Up_conv3", "Up_conv2"]
 PEAK = {"mfma_bf16": 2500.0, "mfma_f32": 157.3, "hbm": 8000.0}  # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
+# What the board SUSTAINS with every matrix pipe full, register-resident random bf16 operands and no memory traffic
+# (profiles/microbench/mfma_sustained.hip, measured in round 2: 1.20-1.26 PFLOP/s at 2-8 waves per SIMD; power-managed).
+SUSTAINED_MFMA_BF16 = 1250.0
 
 
 def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
@@ -424,6 +427,11 @@ def main():
             # cannot be collected in-process).  The file is keyed by kernel name AND library version: numbers taken on another build of
             # the library are ignored (null), never quoted.
             out["roofline"].update(pmc_fields(name, top["flops_per_call"], _cabi.lib().miseg_version(), args))
+            if not mfma_f32:
+                # issued = algorithmic / ceiling_frac: how close the kernel's MFMA issue rate is to what the board sustains
+                cf = out["roofline"].get("ceiling_frac")
+                out["roofline"]["sustained_peak"] = SUSTAINED_MFMA_BF16
+                out["roofline"]["issued_frac_of_sustained"] = round(tf / cf / SUSTAINED_MFMA_BF16, 4) if cf else None
             out["kernel_ms_per_step_warmup"] = {k: round(v["total_ms"] / survey_steps, 3) for k, v in table[:int(os.environ.get("MISEG_BENCH_TOP", "10"))]}
         if world == 1 and not args.no_cpu_baseline:
             try:
