@@ -259,18 +259,22 @@ def test_global_head_fwd_bwd(golden):
     np.testing.assert_allclose(fd.grad.cpu().numpy(), f_ref.grad.numpy(), rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("n,k,h,w,p", [(4, 20, 32, 32, 3), (4, 20, 32, 32, 1), (3, 20, 70, 90, 3), (16, 20, 256, 256, 3)])
+@pytest.mark.parametrize("n,k,h,w,p", [(4, 20, 32, 32, 3), (4, 20, 32, 32, 1), (3, 20, 70, 90, 3), (16, 20, 256, 256, 3),
+                                       (2, 20, 37, 45, 3), (1, 20, 7, 5, 1), (5, 20, 9, 131, 3)])     # odd heights, maps smaller than a tile, 2+ strips with a ragged last one
 def test_joint_bf16_split_matches_fp32_kernel(n, k, h, w, p):
     """bf16-MFMA joint with hi/lo operand split (3 products) vs the exact fp32-MFMA kernel and, for the small shapes,
     the fp64 oracle; plain bf16 (1 product) at bf16 tolerance.  Includes a non-multiple-of-tile shape and a window crop."""
     gen = torch.Generator(device="cpu").manual_seed(n * 1000 + h)
     x = torch.randn(n, k, h, w, generator=gen).softmax(1).to(DEV)
     y = torch.randn(n, k, h, w, generator=gen).softmax(1).to(DEV)
-    for win in ([(0, h, 0, w)], [(3, h - 5, 2, w - 7)] if h < 100 else [(0, h, 0, w)]):
+    for win in ([(0, h, 0, w)], [(3, h - 5, 2, w - 7)] if 12 <= h < 100 else [(0, h, 0, w)]):
         ref = ops().local_mi_raw_joint(x, y, p, win, precision="fp32")
         scale = float(ref.abs().max())
         split = ops().local_mi_raw_joint(x, y, p, win, precision="bf16x3")
-        assert float((split - ref).abs().max()) <= 2e-6 * scale, float((split - ref).abs().max()) / scale
+        # every product carries <= 2^-16 relative error (the lo x lo term is dropped) and all products are positive: the errors average
+        # out over the pixels of a window, so the bound tightens with their number (2e-6 from ~230 pixels on; a 7 x 5 map gets 5e-6)
+        npix = n * (win[0][1] - win[0][0]) * (win[0][3] - win[0][2])
+        assert float((split - ref).abs().max()) <= max(2e-6, 3e-5 / npix ** 0.5) * scale, float((split - ref).abs().max()) / scale
         plain = ops().local_mi_raw_joint(x, y, p, win, precision="bf16")
         assert float((plain - ref).abs().max()) <= 2e-3 * scale, float((plain - ref).abs().max()) / scale
         if h <= 32:
@@ -278,10 +282,10 @@ def test_joint_bf16_split_matches_fp32_kernel(n, k, h, w, p):
                                        y[:, :, win[0][0]:win[0][1], win[0][2]:win[0][3]].double().cpu(), p)
             e_split = float((split[0].double().cpu() - truth).abs().max())
             e_ref = float((ref[0].double().cpu() - truth).abs().max())
-            assert e_split <= 4 * e_ref + 1e-6 * scale, (e_split, e_ref)
+            assert e_split <= 4 * e_ref + max(1e-6, 3e-5 / npix ** 0.5) * scale, (e_split, e_ref)
 
 
-@pytest.mark.parametrize("n,h,w,p", [(4, 32, 32, 3), (4, 32, 32, 1), (3, 70, 90, 3)])
+@pytest.mark.parametrize("n,h,w,p", [(4, 32, 32, 3), (4, 32, 32, 1), (3, 70, 90, 3), (2, 37, 45, 3), (1, 7, 5, 1), (5, 9, 131, 3)])
 def test_local_mi_bf16_split_fwd_bwd_matches_fp64(n, h, w, p):
     """Whole local-MI op (joint -> loss -> backward) in 'bf16x3' precision vs the fp64 oracle: same bounds as the fp32 path."""
     k = 20
