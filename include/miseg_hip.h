@@ -310,6 +310,12 @@ int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_av
  * grad_scale so that activation gradients stay inside half's range): grad is read as grad / grad_scale. */
 int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                            int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale);
+/* ... and guarded: guard = nguard fp32 flags in device memory (the iteration's deferred assertion / NaN flags); if any of them is
+ * non-zero or NaN the launch changes nothing -- parameters and moments stay as the reference, which raises before backward
+ * (iic_loss.py:147-148, semi_seg/epocher.py:129-130), would have left them.  nguard == 0: miseg_adam_step_scaled. */
+int miseg_adam_step_guarded(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                            int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale,
+                            const float* guard, int64_t nguard);
 
 /* ------------------------------------------------------------------------------------------
  * Device input pipeline   ref: semi_seg/augment.py:7-52 (ACDCStrongTransforms),

@@ -371,7 +371,12 @@ __global__ void cast_pad_kernel(const TI* __restrict__ in, TO* __restrict__ out,
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float b1, float b2, const float* __restrict__ hyper,
-                                                   float inv_scale) {
+                                                   float inv_scale, const float* __restrict__ guard, int nguard) {
+    // guard: the iteration's deferred-check flags (non-zero or NaN = a check failed).  A failed check leaves parameters and moments
+    // untouched, so the exception the host raises one iteration later finds the state the reference -- which raises before
+    // backward (iic_loss.py:147-148) -- would have left.
+    for (int i = 0; i < nguard; ++i)
+        if (!(guard[i] == 0.f)) return;
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2], wd = hyper[3];
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * inv_scale + wd * p[i];
@@ -525,14 +530,19 @@ extern "C" int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64
     return MISEG_OK;
 }
 
-extern "C" int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
-                                      float beta1, float beta2, const float* hyper, float grad_scale) {
+extern "C" int miseg_adam_step_guarded(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                                       float beta1, float beta2, const float* hyper, float grad_scale, const float* guard, int64_t nguard) {
     MISEG_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && numel > 0, "adam_step: bad args");
     MISEG_REQUIRE(grad_scale > 0.f && std::isfinite(grad_scale), "adam_step: grad_scale must be a positive finite number");
+    MISEG_REQUIRE(nguard >= 0 && nguard <= 1024 && (nguard == 0 || guard), "adam_step: bad guard");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(numel)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2,
-                       hyper, 1.f / grad_scale);
+                       hyper, 1.f / grad_scale, guard, (int)nguard);
     MISEG_LAUNCH_CHECK("adam_kernel");
     return MISEG_OK;
+}
+extern "C" int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                                      float beta1, float beta2, const float* hyper, float grad_scale) {
+    return miseg_adam_step_guarded(stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, grad_scale, nullptr, 0);
 }
 extern "C" int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                                float beta1, float beta2, const float* hyper) {

@@ -195,13 +195,14 @@ class FusedAdam(torch.optim.Optimizer):
             self._hyper[gi].copy_(host, non_blocking=True)
 
     @torch.no_grad()
-    def apply(self) -> None:
-        """Device half: gather stray gradients into the flat buffer and launch the fused Adam kernel."""
+    def apply(self, guard: Optional[Tensor] = None) -> None:
+        """Device half: gather stray gradients into the flat buffer and launch the fused Adam kernel (a no-op on the device if any
+        of the fp32 flags in ``guard`` is set)."""
         for gi, group in enumerate(self.param_groups):
             fb = self._flats[gi]
             b1, b2 = group["betas"]
             fb.collect()
-            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2, self.grad_scale)
+            unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2, self.grad_scale, guard)
         unet_ops.PACK_CACHE.invalidate()   # the fp32 masters changed: packed operand copies are stale
 
     @torch.no_grad()

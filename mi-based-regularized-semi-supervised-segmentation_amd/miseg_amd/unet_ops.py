@@ -344,9 +344,13 @@ def conv1x1(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
 
 
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, hyper: Tensor, beta1: float, beta2: float,
-              grad_scale: float = 1.0) -> None:
+              grad_scale: float = 1.0, guard: Optional[Tensor] = None) -> None:
     """Fused Adam on flat fp32 buffers; ``hyper`` = device fp32[4] (lr/bc1, 1/sqrt(bc2), eps, weight_decay); ``grad`` is read as
-    grad / grad_scale (the static loss scale of the fp16 mode)."""
+    grad / grad_scale (the static loss scale of the fp16 mode); ``guard`` = fp32 device flags, any non-zero / NaN one turns the launch
+    into a no-op (a failed deferred check must not move the weights)."""
     _need_gpu(param, grad, exp_avg, exp_avg_sq, hyper)
-    call("miseg_adam_step_scaled", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1),
-         float(beta2), _ptr(hyper), float(grad_scale))
+    if guard is not None:
+        _need_gpu(guard)
+        assert guard.dtype == torch.float32 and guard.is_contiguous()
+    call("miseg_adam_step_guarded", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1),
+         float(beta2), _ptr(hyper), float(grad_scale), _ptr(guard), 0 if guard is None else guard.numel())

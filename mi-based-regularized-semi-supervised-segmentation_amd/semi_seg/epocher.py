@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import os
 import random
-from typing import List, Tuple, Union
+from typing import List, Optional, Tuple, Union
 
 import torch
 from torch import Tensor, nn
@@ -43,6 +43,7 @@ from miseg_amd.lazy import LinearLoss
 from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
 
 _DEBUG_ASSERTS = os.environ.get("MISEG_ASSERTS", "0") == "1"
+_GUARD_STEP = os.environ.get("MISEG_GUARD_STEP", "1") != "0"   # a failed deferred check turns the iteration's Adam launch into a no-op
 
 
 def _fused(fn):
@@ -72,6 +73,14 @@ class _Pending:
         """value: a device scalar or a symbolic miseg_amd.lazy.LinearLoss (evaluated with all others at fetch time)."""
         self._names.append(name)
         self._vals.append(value.detach() if isinstance(value, (Tensor, LinearLoss)) else value)
+
+    def guard(self) -> Optional[Tensor]:
+        """The deferred-check flags recorded so far as one fp32 device vector (each lazily recorded flag is evaluated here, once:
+        ``device_values`` reuses the tensors)."""
+        if not self.checks:
+            return None
+        self.checks[:] = [(checks.flag_tensor(c), c[1], c[2]) for c in self.checks]
+        return torch.stack([c[0] for c in self.checks])
 
     def device_values(self) -> Tensor:
         """float32 device vector: the put() values followed by the deferred-check flags (one cat + one mat-vec)."""
@@ -328,7 +337,9 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         if self._reducer is not None:
             self._reducer.finish()
         if hasattr(self._optimizer, "apply"):
-            self._optimizer.apply()
+            # the deferred checks recorded so far (simplex / NaN flags of this iteration) guard the update on the device: the host
+            # raises them one iteration late, but a failed one has not moved the weights (the reference raises before backward)
+            self._optimizer.apply(guard=self._pending.guard() if _GUARD_STEP else None)
         else:
             self._optimizer.step()
         with torch.no_grad():

@@ -320,8 +320,15 @@ def test_deferred_readback_records_every_iteration_like_the_synchronous_one():
         list(pw.parameters())[-1].fill_(float("nan"))   # a head bias: every probability of that tap is NaN -> not a simplex
     ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=STEP["NB"], cur_epoch=0, device=DEV,
                        feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1)
+    opt.flat.ensure()      # the flat buffers are built lazily: force them, then snapshot the parameters
+    snap = opt.flat.flat_param.detach().clone()
     with pytest.raises((RuntimeError, AssertionError)):
         ep.run()
+    # the failed check is raised one iteration late, but it guarded the Adam launches on the device: no weight has moved -- the state
+    # the reference, which raises before backward (iic_loss.py:147-148), leaves behind.  (NaN-free part of the buffer: the poisoned bias.)
+    now = opt.flat.flat_param.detach()
+    keep = ~torch.isnan(snap)
+    assert torch.equal(now[keep], snap[keep]) and bool(torch.isnan(now[~keep]).all())
 
 
 def test_step_graph_replay_equals_eager_steps():
