@@ -57,7 +57,8 @@ class StepState:
 def train_step(state: StepState, labeled_img: Tensor, labeled_tgt: Tensor, unlabeled_img: Tensor, seed: int,
                mode: str = "udaiic", feature_names=("Conv5", "Up_conv3", "Up_conv2"),
                feature_importance=(0.5, 0.25, 0.25), paddings=(1, 3), patch_sizes=(1024, 1024),
-               cons_weight: float = 5.0, iic_weight: float = 0.1, num_classes: int = 4, do_update: bool = True, unet_fn=None):
+               cons_weight: float = 5.0, iic_weight: float = 0.1, num_classes: int = 4, do_update: bool = True, unet_fn=None,
+               head_normalize: bool = False, uda_criterion: str = "mse"):
     """Returns a dict of scalars (meter values) and, if requested, gradients by parameter name.  ``unet_fn`` swaps the network
     evaluation (default ``oracle.unet.unet_forward``; ``unet_forward_bf16_autograd`` emulates the bf16 kernels' rounding points)."""
     params = state.params()
@@ -83,12 +84,12 @@ def train_step(state: StepState, labeled_img: Tensor, labeled_tgt: Tensor, unlab
             f_u, f_tf = torch.chunk(u, 2, 0)                                      # epocher.py:258-259
             hsd = state.heads[fname]
             if fname in ENC:                                                      # epocher.py:261-262
-                probs = H.cluster_head(hsd, torch.cat([f_u, f_tf], 0))
+                probs = H.cluster_head(hsd, torch.cat([f_u, f_tf], 0), normalize=head_normalize)
                 pairs = [torch.chunk(p, 2, 0) for p in probs]
                 ls = [iic.iid_loss(a, b)[0] for a, b in pairs]                    # semi_seg/_utils.py:12-15
             else:
                 f_u_tf = L.apply_flips(f_u, decisions)                            # epocher.py:264-266
-                probs = H.local_cluster_head(hsd, torch.cat([f_u_tf, f_tf], 0))
+                probs = H.local_cluster_head(hsd, torch.cat([f_u_tf, f_tf], 0), normalize=head_normalize)
                 pairs = [torch.chunk(p, 2, 0) for p in probs]
                 ls = [iic.iid_seg_small_patch_loss(a, b, paddings[dec_i], patch_sizes[dec_i]) for a, b in pairs]
                 dec_i += 1
@@ -98,7 +99,10 @@ def train_step(state: StepState, labeled_img: Tensor, labeled_tgt: Tensor, unlab
         for fname, v in zip(feature_names, per_feature):
             out[f"mi/{fname}"] = -v
     if mode in ("uda", "udaiic"):
-        uda = L.softmax_mse(unlabel_tf_logits, unlabel_logits_tf)                 # epocher.py:221-224
+        if uda_criterion == "kl":                                                 # trainer.py:137,194: KL_div()(softmax(a), softmax(b).detach())
+            uda = L.kl_div(unlabel_tf_logits.softmax(1), unlabel_logits_tf.softmax(1).detach())
+        else:
+            uda = L.softmax_mse(unlabel_tf_logits, unlabel_logits_tf)             # epocher.py:221-224
         out["uda"] = uda
     if mode == "udaiic":
         reg = cons_weight * uda + iic_weight * iic_loss                           # epocher.py:323

@@ -33,6 +33,40 @@ def test_main_cli_runs_every_trainer(name, dtype):
         shutil.rmtree(run_dir, ignore_errors=True)
 
 
+def test_main_cli_non_default_iic_configuration():
+    """Everything the reference's YAML lets a user change on the IIC side, at once: four taps at four scales (encoder + three decoder
+    blocks), mlp heads with normalisation, 10 clusters x 3 sub-heads (off the K = 20 fast path: generic fp32-MFMA local-MI kernels),
+    paddings 2 / 1 / 3, 32-pixel patches (overlapping windows), the `kl` consistency criterion -- two tiny epochs must run and
+    produce finite meters (ref config/semi.yaml:40-63, semi_seg/trainer.py:137-160)."""
+    save = "pytest_cli_variants"
+    run_dir = os.path.join(PKG, "semi_seg", "runs", save)
+    shutil.rmtree(run_dir, ignore_errors=True)
+    try:
+        res = subprocess.run(
+            [sys.executable, "semi_seg/main.py", "Trainer.name=udaiic", f"Trainer.save_dir={save}", "Trainer.device=cuda",
+             "Trainer.max_epoch=2", "Trainer.num_batches=2", "Data.size=64", "LabeledData.batch_size=2", "UnlabeledData.batch_size=3",
+             "Arch.compute_dtype=bfloat16", "Trainer.feature_names=[Conv5,Up_conv4,Up_conv3,Up_conv2]",
+             "Trainer.feature_importance=[1,0.5,0.5,0.25]", "UDARegCriterion.name=kl",
+             "IICRegParameters.EncoderParams.head_types=mlp", "IICRegParameters.EncoderParams.normalize=true",
+             "IICRegParameters.EncoderParams.num_clusters=10", "IICRegParameters.EncoderParams.num_subheads=3",
+             "IICRegParameters.DecoderParams.head_types=mlp", "IICRegParameters.DecoderParams.normalize=true",
+             "IICRegParameters.DecoderParams.num_clusters=10", "IICRegParameters.DecoderParams.num_subheads=3",
+             "IICRegParameters.LossParams.paddings=[2,1,3]", "IICRegParameters.LossParams.patch_sizes=32"],
+            cwd=PKG, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        rows = open(os.path.join(run_dir, "storage.csv")).read().splitlines()
+        assert len(rows) == 3
+        header = rows[0].split(",")
+        for row in rows[1:]:
+            vals = dict(zip(header, row.split(",")))
+            for k, v in vals.items():
+                if k.startswith("tra_") and v not in ("",):
+                    assert float(v) == float(v) and abs(float(v)) < 1e6, (k, v)      # finite
+            assert any(k.startswith("tra_individual_mis") or "mi" in k for k in vals)
+    finally:
+        shutil.rmtree(run_dir, ignore_errors=True)
+
+
 def test_trainer_inference_dumps_pngs_and_reports_hausdorff(tmp_path):
     """SemiTrainer.inference (ref semi_seg/trainer.py:109-124 -> InferenceEpocher, epocher.py:76-107)."""
     sys.path.insert(0, PKG)
