@@ -118,11 +118,6 @@ def evaluate(items: Sequence[Union[LinearLoss, Tensor]], passthrough: Sequence[T
                 offset += t.numel()
     tensors = [t for _, t in base.values()]
     dev = tensors[0].device
-    if dev.type == "cuda":      # may run on another stream than the one that produced the values (the epocher's read-back stream)
-        cur = torch.cuda.current_stream(dev)
-        for t in list(tensors) + list(passthrough):
-            if t.is_cuda:
-                t.record_stream(cur)
     with torch.no_grad():
         flat = torch.cat([t.detach().reshape(-1).float() for t in tensors]) if len(tensors) > 1 else tensors[0].detach().reshape(-1).float()
         key = ("m", str(dev), tuple((tuple((base[id(t)][0], t.numel(), c) for t, c in it.terms)) for it in items), offset)

@@ -103,26 +103,15 @@ class _Pending:
         checks.raise_failed(items, host[len(out):])
         return out
 
-    def post(self, extras=(), stream=None):
-        """``stream``: a side stream to do all of this on (it first waits for the current stream): the dozen one-element kernels of
-        the read-back then run beside the next iteration's input staging instead of in front of it.
-        Start the asynchronous copy of this iteration's scalars (and deferred-check flags) into pinned host memory and
+    def post(self, extras=()):
+        """Start the asynchronous copy of this iteration's scalars (and deferred-check flags) into pinned host memory and
         return a ticket for ``wait``; ``extras`` (device tensors, e.g. the Dice counts) travel the same way and come back as
         the ticket's host tensors.  The training loop waits for iteration i's ticket only after iteration i+1 is enqueued,
         so the host never drains the GPU queue: a per-iteration ``fetch()`` left the first ~0.25 ms of every step's launches
         exposed."""
-        if stream is not None:
-            stream.wait_stream(torch.cuda.current_stream(stream.device))
-            with torch.cuda.stream(stream):
-                for t in extras:
-                    if t.is_cuda:
-                        t.record_stream(stream)          # produced on the main stream, read here
-                return self.post(extras)
         if self._static is not None:
             names, scalars, items = self._static
             self._static = None
-            if scalars.is_cuda:
-                scalars.record_stream(torch.cuda.current_stream(scalars.device))
         elif not self._vals and not self.checks:
             names, scalars, items = [], None, []
         else:
@@ -382,23 +371,11 @@ class TrainEpocher(_num_class_mixin, _Epocher):
     _inflight = None
 
     def _after_step(self, inter: Tensor, union: Tensor, label_group) -> None:
-        prev, self._inflight = self._inflight, (self._pending.post((inter, union), self._post_stream(inter)), label_group)
+        prev, self._inflight = self._inflight, (self._pending.post((inter, union)), label_group)
         if not self._DEFER_FETCH:
             self._flush_records()
         elif prev is not None:
             self._record_ticket(*prev)
-
-    _POST_STREAM = os.environ.get("MISEG_POST_STREAM", "1") != "0"
-    _post_streams: dict = {}
-
-    def _post_stream(self, like: Tensor):
-        """Side stream for the read-back's small kernels (one per device, shared by all epochers)."""
-        if not (self._POST_STREAM and like.is_cuda):
-            return None
-        s = TrainEpocher._post_streams.get(like.device)
-        if s is None:
-            s = TrainEpocher._post_streams[like.device] = torch.cuda.Stream(like.device)
-        return s
 
     def _flush_records(self) -> None:
         last, self._inflight = self._inflight, None
