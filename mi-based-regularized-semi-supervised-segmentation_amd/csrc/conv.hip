@@ -553,6 +553,17 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_S16X4(ptr) ((__attribute__((address_space(3))) s16x4*)(ptr))
 
+// The same for a 32-pixel k-step of v_mfma_f32_16x16x32_bf16 with the k <-> pixel map  k = 8 kq + e  <->  pixel 16 (e >> 2) + 4 kq + (e & 3)
+// (any bijection does, A and B share it): per transpose read the two lane groups of a half-wave (kq = 0, 1 or 2, 3) cover 8
+// CONSECUTIVE pixels x 32 B = every bank once.  With pixel = 8 kq + e they read pixels 0-3 and 8-11, 256 B apart: a 2-way conflict
+// on every read (38 % of conv3x3_wgrad_bf16_c16_kernel's LDS cycles, profiles/r02_pmc.json).
+__device__ __forceinline__ bf16x8_t tr_frag32(const short* row_px0, int kq, int q, int p) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row_px0 + (4 * kq + q) * 16 + 4 * p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row_px0 + (16 + 4 * kq + q) * 16 + 4 * p));
+    s16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, f);
+}
+
 __device__ __forceinline__ bf16x8_t tr_frag(const short* blk_px0, int q, int p) {
     // blk_px0: first pixel (of this lane group's 8) of a [pixel][16] sub-tile
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(blk_px0 + q * 16 + 4 * p));
@@ -565,8 +576,13 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
                                                                    int Cout, int nsplit, float* __restrict__ partials) {
     constexpr int IW = WG_TW + 2, NPX = WG_TH * WG_TW, NIPX = (WG_TH + 2) * IW;
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
-    short* Gs = reinterpret_cast<short*>(wsm_raw);            // [2][NPX][16]
-    short* Is = Gs + 2 * NPX * 16;                            // [2][NIPX][16]
+    // The two 16-channel sub-tiles of a half-wave's transpose read (lanes 0-15 | 16-31) must land in different 128-byte bank windows:
+    // NPX * 32 B = 8 KB is a multiple of the 256-byte bank period, so the second sub-tile of Gs starts 128 B late (GSUB); NIPX * 32 B
+    // = 10 880 B already is 128 (mod 256).  Unpadded, 31 % of this kernel's LDS cycles were 2-way conflicts (profiles/r02_pmc.json).
+    constexpr int GSUB = NPX * 16 + 64;
+    short* Gs = reinterpret_cast<short*>(wsm_raw);            // [2][GSUB]: [NPX][16] twice
+    short* Is = Gs + 2 * GSUB;                                // [2][NIPX][16]
+    static_assert((NIPX * 32) % 256 == 128, "Is sub-tiles: re-check the bank offset for this tile shape");
     const int Cin = src.C0 + src.C1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int g8 = 8 * kq, q = (lane >> 2) & 3, p4 = lane & 3;
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2;
-            *reinterpret_cast<uint4*>(Gs + ((v >> 1) * NPX + px) * 16 + (v & 1) * 8) = pg[j];
+            *reinterpret_cast<uint4*>(Gs + (v >> 1) * GSUB + px * 16 + (v & 1) * 8) = pg[j];
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -641,7 +657,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
         if (tile + nsplit < ntiles) fetch(tile + nsplit);
 #pragma unroll 2
         for (int row = 0; row < WG_TH; ++row) {
-            const short* gb = Gs + (chh * NPX + row * WG_TW + 8 * pxh) * 16;
+            const short* gb = Gs + chh * GSUB + (row * WG_TW + 8 * pxh) * 16;
             const bf16x8_t a0 = tr_frag(gb, q, p4), a1 = tr_frag(gb + 16 * 16, q, p4);     // pixels 0-15 | 16-31 of the row
             const short* ib = Is + (chh * NIPX + row * IW + 8 * pxh) * 16;
             {
@@ -697,7 +713,7 @@ __global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc 
     short* Is = Gs + NPX * 16;                                // [NIPX][16]
     const int Cin = src.C0 + src.C1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int g8 = 8 * kq, q = (lane >> 2) & 3, p4 = lane & 3;
+    const int q = (lane >> 2) & 3, p4 = lane & 3;
     const int split = blockIdx.x, ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16;
     const int tilesC = (W + WG_TW - 1) / WG_TW, tilesR = (H + WG_TH - 1) / WG_TH;
     const int ntiles = N * tilesR * tilesC;
@@ -755,11 +771,11 @@ __global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc 
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row = wv * 2 + rr;
-            const bf16x8_t a0 = tr_frag(Gs + (row * WG_TW + g8) * 16, q, p4);
+            const bf16x8_t a0 = tr_frag32(Gs + row * WG_TW * 16, kq, q, p4);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                const bf16x8_t b0 = tr_frag(Is + ((row + ky) * IW + g8 + kx) * 16, q, p4);
+                const bf16x8_t b0 = tr_frag32(Is + ((row + ky) * IW + kx) * 16, kq, q, p4);
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[tap], 0, 0, 0);
             }
         }
@@ -1067,7 +1083,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<float>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws);
     } else if (dt == MISEG_BF16) {
         MISEG_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "conv3x3_wgrad: bf16 needs channel counts that are multiples of 8");
-        const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2, (size_t)(32 * 288 + 4 * 1024) * 4);
+        const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2 + 2 * 64 * 2, (size_t)(32 * 288 + 4 * 1024) * 4);
         // narrow layers (measured per shape, scratch/time_conv.py): the lean 16x16-tile kernel wins when one side has <= 16
         // channels (256^2 16->16: 125 -> 52 us, 32->16: 129 -> 83, 128^2 16->32: 85 -> 48) and for 32->64 (71 -> 53);
         // from 32->32 up the 32x32-tile kernel's operand reuse wins
