@@ -238,6 +238,13 @@ int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int
 int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
                       int ups1, int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out,
                       float* stats_partials);
+/* conv3x3 whose output leaves 2x2 SUM-pooled: out_pooled NHWC [N, H/2, W/2, Cout].  With pack kind 1 this is the data gradient of a
+ * convolution that read its input through the nearest x2 upsample (unet.py:32): conv3x3_fwd + miseg_sumpool2x2 without the
+ * full-resolution intermediate (4x the bytes of the result); the four fp32 sums of a block are added before the one rounding.
+ * Single source, bf16 / fp16, the streaming shapes only (Cin <= 32, large maps): ask _supported, else use the two calls. */
+int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
+int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
+                              const void* packed_w, int64_t Cout, void* out_pooled);
 /* conv3x3_fwd + bn_finalize in ONE launch (training mode): the block that finishes last sums the partial rows and writes
  * `saved` / the running statistics itself (same formulas as miseg_bn_finalize; the sums are combined in a different but fixed
  * order).  sync_counter: one int32 in device memory, 0 on entry, 0 again when the kernel ends -- the caller may hand the same

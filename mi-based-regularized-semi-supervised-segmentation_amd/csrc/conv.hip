@@ -221,7 +221,10 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
 // XCD works on in a sweep are contiguous and their halos hit that XCD's L2.
 // DUAL (concat of two sources): slots are vector-major so that one load instruction reads one source.
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-template <int COT, int TW, int NVEC, bool DUAL>
+// POOL: the output leaves 2x2 sum-pooled ([N, H/2, W/2, Cout]; H, W even) -- the backward of a convolution whose input was read
+// through a nearest x2 upsample: its data gradient at full resolution (4x the bytes of what is wanted) is never written; the four
+// fp32 accumulators of a 2x2 block are added (two registers of the lane, then its neighbour's sum) and rounded once.
+template <int COT, int TW, int NVEC, bool DUAL, bool POOL = false>
 __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ wpk, int Cout,
                                                                bf16* __restrict__ out, float* __restrict__ stats, int ntiles, BnFinish fin) {
     typedef bf16 T;
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
 
     // The epilogue of tile i is issued one iteration late (from packed registers), in front of the next loads: the
     // s_waitcnt vmcnt(0) guarding the register->LDS commit then only sees memory operations one MFMA phase old.
-    uint2 pk[MTW][NT];
+    constexpr int MPK = POOL ? MTW / 2 : MTW;            // POOL: (pooled row 0 / 1 of the wave's four rows) x (16-column block)
+    uint2 pk[MPK][NT];
     float s1[NT][4], s2[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -311,6 +315,26 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         const int tc = ptile % tilesC, tr = (ptile / tilesC) % tilesR, n = ptile / (tilesC * tilesR);
         const int h0 = tr * TH, w0 = tc * TW;
         const bool full = h0 + TH <= H && w0 + TW <= W && co0 + COT <= Cout;
+        if (POOL) {     // even lanes hold the sums of their 2x2 block: pooled pixel (h0/2 + 2 wv + pr, w0/2 + 8 mc + l15/2)
+            const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+            for (int mp = 0; mp < MPK; ++mp) {
+                const int hp = (h0 >> 1) + wv * 2 + mp / MTR, wp = (w0 >> 1) + (mp % MTR) * 8 + (l15 >> 1);
+                if ((l15 & 1) || hp >= Hp || wp >= Wp) continue;
+                T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout + co0 + kq * 4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (co0 + t * 16 + kq * 4 + 4 <= Cout) *reinterpret_cast<uint2*>(op + t * 16) = pk[mp][t];
+                    else {
+                        const T* e = reinterpret_cast<const T*>(&pk[mp][t]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + t * 16 + kq * 4 + r < Cout) op[t * 16 + r] = e[r];
+                    }
+                }
+            }
+            return;
+        }
         T* ob = out + (((size_t)n * H + h0 + wv * 4) * W + w0 + l15) * Cout + co0 + kq * 4;
         if (full) {
 #pragma unroll
@@ -367,6 +391,25 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         }
         // D^T[row = channel t*16 + kq*4 + r][col = pixel l15]: pack to bf16, accumulate the BN statistics of valid outputs
         const bool full = h0 + TH <= H && w0 + TW <= W && co0 + COT <= Cout;
+        if (POOL) {
+#pragma unroll
+            for (int mp = 0; mp < MPK; ++mp) {
+                const int m0 = (2 * (mp / MTR)) * MTR + mp % MTR, m1 = m0 + MTR;       // rows 2 pr and 2 pr + 1, same column block
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    T e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[m0][t][r] + acc[m1][t][r];
+                        v += __shfl_xor(v, 1, 64);                                    // the column neighbour (lane l15 ^ 1)
+                        e[r] = from_f32<T>(v);
+                    }
+                    pk[mp][t] = *reinterpret_cast<const uint2*>(e);
+                }
+            }
+            ptile = tile;
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
@@ -973,7 +1016,8 @@ extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int
 }
 
 static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
-                            int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats, BnFinish fin) {
+                            int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats, BnFinish fin,
+                            bool pool_out = false) {
     MISEG_REQUIRE(in0 && packed_w && out, "conv3x3_fwd: null pointer");
     MISEG_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0, "conv3x3_fwd: bad shape");
     MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_fwd: second source missing");
@@ -994,14 +1038,22 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
                            (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats, fin);                                  \
     }
 #define LAUNCH(TT, COT, TWW) { if (th == 8) LAUNCH_TH(TT, COT, TWW, 8) else LAUNCH_TH(TT, COT, TWW, 16) }
+    MISEG_REQUIRE(!pool_out || (conv_streams(dt, C0 + C1, N, H, W) && C1 == 0 && !stats && H % 2 == 0 && W % 2 == 0),
+                  "conv3x3_fwd_sumpool: shape not supported (ask miseg_conv3x3_fwd_sumpool_supported)");
     if (conv_streams(dt, C0 + C1, N, H, W)) {
 #define SLAUNCH(COT, NV, DU)                                                                                               \
     {                                                                                                                     \
         size_t lb = ((size_t)(TH + 2) * (32 + 2) * (COT == 16 ? 48 : Mma<bf16>::CKP) + 9 * COT * Mma<bf16>::CKP) * sizeof(bf16);      \
         const unsigned g = (unsigned)stream_blocks(N, H, W);                                                               \
+        if (pool_out && !DU) {                                                                                           \
+            hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+            hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, false, true>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, \
+                               (int)H, (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx, fin);              \
+        } else {                                                                                                         \
         hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
         hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, DU>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
                            (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx, fin);                      \
+        }                                                                                                                \
     }
 #define SLAUNCH_NV(COT)                                                                                                    \
     {                                                                                                                     \
@@ -1032,6 +1084,16 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
                                  int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats) {
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats);
     return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, BnFinish{});
+}
+
+extern "C" int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
+    return conv_streams(dt == MISEG_F16 ? MISEG_BF16 : dt, Cin, N, H, W) && H % 2 == 0 && W % 2 == 0;
+}
+
+extern "C" int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
+                                         const void* packed_w, int64_t Cout, void* out_pooled) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_sumpool, stream, MISEG_BF16, in, Cin, N, H, W, packed_w, Cout, out_pooled);
+    return conv3x3_fwd_impl(stream, dt, in, Cin, 0, nullptr, 0, 0, N, H, W, packed_w, Cout, out_pooled, nullptr, BnFinish{}, true);
 }
 
 // The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.

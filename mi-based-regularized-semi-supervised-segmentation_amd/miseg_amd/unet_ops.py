@@ -47,6 +47,9 @@ def join_wgrad_streams() -> None:
     _wgrad_dirty.clear()
 
 
+_FUSE_UPS_DGRAD = os.environ.get("MISEG_FUSE_UPS_DGRAD", "1") != "0"   # A/B switch: 0 = conv3x3 dgrad + miseg_sumpool2x2 as two launches
+
+
 class _SyncCounters:
     """int32 counters for the "last block finishes" launches (miseg_conv3x3_bn_fwd, miseg_bn_relu_bwd_sync): zero when a launch
     starts, zero again when it ends.  One zero-filled array per device, handed out round-robin, so that launches which could overlap
@@ -291,6 +294,15 @@ class _ConvBNReLU(torch.autograd.Function):
             if xs is None or not ctx.needs_input_grad[s]:
                 continue
             packed = _pack(weight, dtype, 1, cb, cs)
+            if ups and _FUSE_UPS_DGRAD and query("miseg_conv3x3_fwd_sumpool_supported", _DT[dtype], cout, n, h, w):
+                # the source was read through the x2 upsample: its gradient is the 2x2 sum-pool of the data gradient -- pooled in the
+                # convolution's epilogue, the full-resolution gradient (4x the bytes) never exists
+                glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
+                call("miseg_conv3x3_fwd_sumpool", _stream(), _DT[dtype], _ptr(graw), cout, n, h, w, _ptr(packed), cs, _ptr(glow),
+                     work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs / 4 + cout)),
+                     tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+                grads[s] = glow
+                continue
             gfull = empty_nhwc(n, cs, h, w, dtype, dev)
             call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(graw), cout, 0, None, 0, 0, n, h, w, _ptr(packed), cs, _ptr(gfull), None,
                  work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs + cout)), tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")

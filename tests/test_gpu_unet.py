@@ -265,3 +265,37 @@ def test_bn_statistics_finished_by_the_last_block_equal_the_separate_finalize(sh
             assert err <= tol, (name, err)
     if unet_ops.SYNC_COUNTERS._pool:
         assert all(int(p.abs().sum()) == 0 for p in unet_ops.SYNC_COUNTERS._pool.values())      # every counter is back at zero
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(4, 256, 256, 32, 16), (16, 128, 128, 32, 32), (6, 250, 230, 16, 32)])
+def test_upsampled_source_gradient_pooled_in_the_dgrad_epilogue(shape, dtype, monkeypatch):
+    """Backward of a convolution that reads its input through the nearest x2 upsample (ref unet.py:32): the source gradient is the
+    2x2 sum-pool of the full-resolution data gradient.  `miseg_conv3x3_fwd_sumpool` pools the fp32 accumulators in the epilogue; the
+    two-launch form (conv3x3 dgrad -> miseg_sumpool2x2) rounds every full-resolution value to 16 bits first.  Both against the fp32
+    oracle: the fused form must be at least as close, and the two must agree to the two-rounding bound (incl. a ragged shape)."""
+    from miseg_amd import unet_ops
+    n, h, w, cin, cout = shape
+    x = nhwc(T(synth.normal(f"upsd/{shape}/x", (n, cin, h // 2, w // 2))).to(DEV).to(dtype))
+    wt = T(synth.normal(f"upsd/{shape}/w", (cout, cin, 3, 3), scale=(2.0 / (cin * 9)) ** 0.5))
+    cot = T(synth.normal(f"upsd/{shape}/cot", (n, cout, h, w)))
+    bn = make_bn(cout, f"upsd/{shape}/bn")
+
+    def run(fused):
+        monkeypatch.setattr(unet_ops, "_FUSE_UPS_DGRAD", fused)
+        b = {k: v.clone().to(DEV) for k, v in bn.items()}
+        xd = x.clone().requires_grad_(True)
+        y, _ = unet_ops.conv_bn_relu(xd, None, wt.to(DEV).requires_grad_(True), b["weight"].requires_grad_(True), b["bias"].requires_grad_(True),
+                                     b["running_mean"], b["running_var"], b["nbt"], True, 1, 0, False)
+        (y.float() * cot.to(DEV)).sum().backward()
+        return xd.grad.float().cpu()
+
+    fused, two = run(True), run(False)
+    xr = x.float().cpu().requires_grad_(True)
+    yr, _, _, _ = ref_layer(F.interpolate(xr, scale_factor=2, mode="nearest"), wt.to(dtype).float(), bn, True, False)
+    (yr * cot).sum().backward()
+    scale = float(xr.grad.abs().max())
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert float((fused - two).abs().max()) <= 4 * ulp * scale
+    e_fused, e_two = float((fused - xr.grad).abs().mean()), float((two - xr.grad).abs().mean())
+    assert e_fused <= 1.05 * e_two + 1e-9, (e_fused, e_two)
