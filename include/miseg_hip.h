@@ -241,8 +241,9 @@ int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups
 /* conv3x3 whose output leaves 2x2 SUM-pooled: out_pooled NHWC [N, H/2, W/2, Cout].  With pack kind 1 this is the data gradient of a
  * convolution that read its input through the nearest x2 upsample (unet.py:32): conv3x3_fwd + miseg_sumpool2x2 without the
  * full-resolution intermediate (4x the bytes of the result); the four fp32 sums of a block are added before the one rounding.
- * Single source, bf16 / fp16, the streaming shapes only (Cin <= 32, large maps): ask _supported, else use the two calls. */
-int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
+ * Single source, bf16 / fp16; the streaming shapes (Cin <= 32, large maps) and the tiled kernel's 64-channel-slice form (Cout > 32):
+ * ask _supported, else use the two calls. */
+int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout);
 int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
                               const void* packed_w, int64_t Cout, void* out_pooled);
 /* conv3x3_fwd + bn_finalize in ONE launch (training mode): the block that finishes last sums the partial rows and writes

@@ -55,7 +55,8 @@ __device__ __forceinline__ void zero_vec(T* dst) {
 }
 
 // COT: output channels per block; TW: tile width (32 or 16).  grid = (N*tilesR*tilesC, ceil(Cout/COT)).
-template <typename T, int COT, int TW, int THT>
+// POOL: as in conv3x3_stream_kernel below -- the output leaves 2x2 sum-pooled (H, W even; no statistics).
+template <typename T, int COT, int TW, int THT, bool POOL = false>
 __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
                                                         T* __restrict__ out, float* __restrict__ stats, BnFinish fin) {
     typedef Mma<T> MM;
@@ -147,6 +148,38 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
     }
     // ---- epilogue: D^T[row = channel t*16 + kq*4 + r][col = pixel l15]: a lane owns 4 consecutive channels of one pixel, so
     // the 16 lanes x 4 kq of a wave store whole NHWC pixel vectors (8-byte pieces, contiguous across kq)
+    if (POOL) {      // rows 2 pr, 2 pr + 1 of the wave (two registers of the lane) + the column neighbour's sum; even lanes store
+        static_assert(!POOL || RW % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
+        const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+        for (int mp = 0; mp < MTW / 2; ++mp) {
+            const int m0 = (2 * (mp / MTR)) * MTR + mp % MTR, m1 = m0 + MTR;
+            const int hp = ((h0 + wv * RW) >> 1) + mp / MTR, wp = ((w0 + (mp % MTR) * 16) >> 1) + (l15 >> 1);
+            const bool mine = !(l15 & 1) && hp < Hp && wp < Wp;
+            T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co0 + t * 16 + kq * 4;
+                T pk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[m0][t][r] + acc[m1][t][r];
+                    v += __shfl_xor(v, 1, 64);
+                    pk[r] = from_f32<T>(v);
+                }
+                if (!mine) continue;
+                if (co + 3 < Cout) {
+                    if (sizeof(T) == 2) *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                    else *reinterpret_cast<uint4*>(op + co) = *reinterpret_cast<const uint4*>(pk);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < Cout) op[co + r] = pk[r];
+                }
+            }
+        }
+        return;
+    }
     float s1[NT][4], s2[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -1015,6 +1048,12 @@ extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int
     return N * cdiv(H, generic_tile_h(dt, H, W)) * cdiv(W, tw);
 }
 
+// pooled-output forms exist for the streaming shapes and, in the tiled kernel, for 16-bit storage with more than 32 output channels
+static bool sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
+    if (H % 2 || W % 2) return false;
+    return conv_streams(dt, Cin, N, H, W) || (dt == MISEG_BF16 && Cout > 32);
+}
+
 static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                             int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats, BnFinish fin,
                             bool pool_out = false) {
@@ -1038,7 +1077,7 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
                            (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats, fin);                                  \
     }
 #define LAUNCH(TT, COT, TWW) { if (th == 8) LAUNCH_TH(TT, COT, TWW, 8) else LAUNCH_TH(TT, COT, TWW, 16) }
-    MISEG_REQUIRE(!pool_out || (conv_streams(dt, C0 + C1, N, H, W) && C1 == 0 && !stats && H % 2 == 0 && W % 2 == 0),
+    MISEG_REQUIRE(!pool_out || (sumpool_supported(dt, C0 + C1, N, H, W, Cout) && C1 == 0 && !stats),
                   "conv3x3_fwd_sumpool: shape not supported (ask miseg_conv3x3_fwd_sumpool_supported)");
     if (conv_streams(dt, C0 + C1, N, H, W)) {
 #define SLAUNCH(COT, NV, DU)                                                                                               \
@@ -1066,6 +1105,17 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
         else SLAUNCH_NV(32)
 #undef SLAUNCH_NV
 #undef SLAUNCH
+    } else if (dt == MISEG_BF16 && pool_out) {
+#define LAUNCH_P(TWW, THH)                                                                                                 \
+    {                                                                                                                     \
+        size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * 64) * Mma<bf16>::KP * sizeof(bf16);                               \
+        hipFuncSetAttribute((const void*)conv3x3_kernel<bf16, 64, TWW, THH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_kernel<bf16, 64, TWW, THH, true>), dim3(gx, (unsigned)cdiv(Cout, 64)), dim3(kCT), lb, st, s, (int)N, (int)H, \
+                           (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, fin);                               \
+    }
+        if (tw == 32) { if (th == 8) LAUNCH_P(32, 8) else LAUNCH_P(32, 16) }
+        else { if (th == 8) LAUNCH_P(16, 8) else LAUNCH_P(16, 16) }
+#undef LAUNCH_P
     } else if (dt == MISEG_BF16) {
         if (Cout <= 16) { if (tw == 32) LAUNCH(bf16, 16, 32) else LAUNCH(bf16, 16, 16) }
         else if (Cout <= 32) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
@@ -1086,8 +1136,8 @@ extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t 
     return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, BnFinish{});
 }
 
-extern "C" int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
-    return conv_streams(dt == MISEG_F16 ? MISEG_BF16 : dt, Cin, N, H, W) && H % 2 == 0 && W % 2 == 0;
+extern "C" int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
+    return sumpool_supported(dt == MISEG_F16 ? MISEG_BF16 : dt, Cin, N, H, W, Cout);
 }
 
 extern "C" int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,

@@ -294,7 +294,7 @@ class _ConvBNReLU(torch.autograd.Function):
             if xs is None or not ctx.needs_input_grad[s]:
                 continue
             packed = _pack(weight, dtype, 1, cb, cs)
-            if ups and _FUSE_UPS_DGRAD and query("miseg_conv3x3_fwd_sumpool_supported", _DT[dtype], cout, n, h, w):
+            if ups and _FUSE_UPS_DGRAD and query("miseg_conv3x3_fwd_sumpool_supported", _DT[dtype], cout, n, h, w, cs):
                 # the source was read through the x2 upsample: its gradient is the 2x2 sum-pool of the data gradient -- pooled in the
                 # convolution's epilogue, the full-resolution gradient (4x the bytes) never exists
                 glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)

@@ -268,7 +268,8 @@ def test_bn_statistics_finished_by_the_last_block_equal_the_separate_finalize(sh
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(4, 256, 256, 32, 16), (16, 128, 128, 32, 32), (6, 250, 230, 16, 32)])
+@pytest.mark.parametrize("shape", [(4, 256, 256, 32, 16), (16, 128, 128, 32, 32), (6, 250, 230, 16, 32),
+                                   (8, 64, 64, 128, 64), (8, 32, 32, 256, 128), (3, 20, 36, 64, 64)])     # the last three: tiled kernel, 64-channel slices
 def test_upsampled_source_gradient_pooled_in_the_dgrad_epilogue(shape, dtype, monkeypatch):
     """Backward of a convolution that reads its input through the nearest x2 upsample (ref unet.py:32): the source gradient is the
     2x2 sum-pool of the full-resolution data gradient.  `miseg_conv3x3_fwd_sumpool` pools the fp32 accumulators in the epilogue; the
