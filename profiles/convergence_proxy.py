@@ -70,7 +70,7 @@ def run_product(dtype, data, args):
     from semi_seg._utils import IICLossWrapper, ProjectorWrapper
     from semi_seg.epocher import UDAIICEpocher
     dev = "cuda"
-    ops.set_mi_precision("bf16x3" if dtype == "bfloat16" else "fp32")
+    ops.set_mi_precision("bf16x3" if dtype in ("bfloat16", "float16") else "fp32")
     model = UNet(1, 4, compute_dtype=dtype)
     model.load_state_dict(OU.init_state(1, 4, seed=21 + 100 * args.run_seed))
     pw = ProjectorWrapper()
@@ -178,7 +178,7 @@ def main():
             else:
                 from miseg_amd import _cabi
                 _cabi.lib()
-                curve = run_product({"bf16": "bfloat16", "fp32": "float32"}[arm], data, args)
+                curve = run_product({"bf16": "bfloat16", "fp16": "float16", "fp32": "float32"}[arm], data, args)
             out["arms"][f"{arm}/seed{sd}"] = {"curve": curve, "seconds": round(time.time() - t0, 1)}
             json.dump(out, open(args.out, "w"), indent=1)
     # plateau value of a run = mean of its last two evaluations; per arm: mean and spread over the run seeds
