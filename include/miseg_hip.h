@@ -205,6 +205,14 @@ int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, in
 int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
                       int64_t C, int64_t* pred, int64_t* inter, int64_t* uni);
 
+/* The iteration's scalar report in one launch   ref: the .item() reads of semi_seg/epocher.py:115-121 and the inline
+ * `if torch.isnan(loss): raise` / `assert simplex(..)` of iic_loss.py:28-29,132-133,184-186.
+ * flat[>= C] fp32 (first C entries = the distinct device scalars the R reported values are linear combinations of, coeff[R][C];
+ * further entries = vectors that are NaN-tested / float flags), iflat = int32 flags; desc[ncheck][3] = (kind, a, b):
+ * 0 -> flat[a], 1 -> number of NaNs in flat[a .. a+b), 2 -> (float) iflat[a].  out[R + ncheck]: values (a non-finite input
+ * poisons exactly the rows that use it), then the check flags in desc order. */
+int miseg_report_scalars(void* stream, const float* flat, const int32_t* iflat, const float* coeff, int64_t R, int64_t C,
+                         const int32_t* desc, int64_t ncheck, float* out);
 /* counts the positions of x[outer][C][inner] (fp32) whose channel sum is not within tol of 1 (NaN counts): the device
  * half of `simplex` (ref whl:deepclustering2/utils/general.py simplex = allclose(sum(axis), 1)); adds into *count. */
 int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_t C, int64_t inner, float tol,

@@ -199,9 +199,53 @@ __global__ __launch_bounds__(256) void simplex_violations_kernel(const float* __
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
 }
 
+
+// The iteration's host report in ONE launch (was ~20 one-element torch kernels at the head of every step: isfinite / where / two
+// mat-vecs / isnan-sum-cast per check / casts / cats).  flat = the distinct device scalars (and the vectors that are NaN-tested), one
+// torch.cat; row r of coeff = the linear combination a reported value is (miseg_amd.lazy.LinearLoss).  out[0 .. R) = the values --
+// a non-finite entry poisons exactly the rows that use it (0 * NaN must not reach the others) --, out[R + j] = check flag j:
+// desc[j] = (kind, a, b): 0 = flat[a] as is, 1 = number of NaNs in flat[a .. a + b), 2 = (float) iflat[a].
+__global__ __launch_bounds__(256) void report_scalars_kernel(const float* __restrict__ flat, const int32_t* __restrict__ iflat,
+                                                             const float* __restrict__ coeff, int R, int C,
+                                                             const int32_t* __restrict__ desc, int ncheck, float* __restrict__ out) {
+    for (int r = threadIdx.x; r < R; r += 256) {
+        float acc = 0.f;
+        bool bad = false;
+        for (int c = 0; c < C; ++c) {
+            const float k = coeff[(size_t)r * C + c], v = flat[c];
+            if (k != 0.f) {
+                if (isfinite(v)) acc += k * v;
+                else bad = true;
+            }
+        }
+        out[r] = bad ? __int_as_float(0x7FC00000) : acc;
+    }
+    for (int j = threadIdx.x; j < ncheck; j += 256) {
+        const int kind = desc[3 * j], a = desc[3 * j + 1], b = desc[3 * j + 2];
+        float f;
+        if (kind == 0) f = flat[a];
+        else if (kind == 2) f = (float)iflat[a];
+        else {
+            int n = 0;
+            for (int e = 0; e < b; ++e) n += isnan(flat[a + e]) ? 1 : 0;
+            f = (float)n;
+        }
+        out[R + j] = f;
+    }
+}
+
 }  // namespace miseg
 
 using namespace miseg;
+
+extern "C" int miseg_report_scalars(void* stream, const float* flat, const int32_t* iflat, const float* coeff, int64_t R, int64_t C,
+                                    const int32_t* desc, int64_t ncheck, float* out) {
+    MISEG_REQUIRE(out && R >= 0 && C >= 0 && ncheck >= 0 && R + ncheck > 0, "report_scalars: bad sizes");
+    MISEG_REQUIRE((R == 0 || (coeff && (C == 0 || flat))) && (ncheck == 0 || desc), "report_scalars: null pointer");
+    hipLaunchKernelGGL(report_scalars_kernel, dim3(1), dim3(256), 0, as_stream(stream), flat, iflat, coeff, (int)R, (int)C, desc, (int)ncheck, out);
+    MISEG_LAUNCH_CHECK("report_scalars_kernel");
+    return MISEG_OK;
+}
 
 extern "C" int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_t C, int64_t inner, float tol,
                                         int32_t* count) {

@@ -36,6 +36,22 @@ class deferred:
         return False
 
 
+class LazyFlag:
+    """A check whose 0-d float flag has not been computed yet: ``kind`` 'nan' (number of NaNs in ``tensor``) or 'cast' (``tensor`` is
+    a 0-d count of another dtype).  Calling it computes the flag with torch ops (a few one-element launches); the iteration's
+    fused report (miseg_amd.lazy.report -> miseg_report_scalars) reads ``tensor`` directly instead."""
+    __slots__ = ("kind", "tensor")
+
+    def __init__(self, kind: str, tensor: Tensor):
+        self.kind, self.tensor = kind, tensor
+
+    def __call__(self) -> Tensor:
+        t = self.tensor
+        if t.is_cuda:
+            t.record_stream(torch.cuda.current_stream(t.device))   # produced on the branch stream, read here
+        return torch.isnan(t).sum().reshape(()).float() if self.kind == "nan" else t.reshape(()).float()
+
+
 def require_zero(bad: Tensor, exc, msg: str) -> None:
     """Fail with ``exc(msg)`` if the 0-d device tensor ``bad`` is non-zero (now, or at the enclosing block's fetch)."""
     if _active is None:
@@ -46,11 +62,7 @@ def require_zero(bad: Tensor, exc, msg: str) -> None:
         if b.dtype == torch.float32 and b.dim() == 0:
             _active.append((b, exc, msg))
         else:   # the cast is one more tiny launch: issued when the flags are gathered, not here (see raise_if_nan)
-            def flag() -> Tensor:
-                if b.is_cuda:
-                    b.record_stream(torch.cuda.current_stream(b.device))
-                return b.reshape(()).float()
-            _active.append((flag, exc, msg))
+            _active.append((LazyFlag("cast", b), exc, msg))
 
 
 def raise_failed(items: List[_Item], host_flags) -> None:
@@ -95,13 +107,7 @@ def raise_if_nan(values: Tensor, describe: str = "nan loss") -> None:
     if _active is None:
         require_zero(torch.isnan(values).sum(), RuntimeError, describe)
         return
-    v = values.detach()
-
-    def count() -> Tensor:
-        if v.is_cuda:
-            v.record_stream(torch.cuda.current_stream(v.device))   # produced on the branch stream, read here
-        return torch.isnan(v).sum().reshape(()).float()
-    _active.append((count, RuntimeError, describe))
+    _active.append((LazyFlag("nan", values.detach()), RuntimeError, describe))
 
 
 def flag_tensor(item: _Item) -> Tensor:

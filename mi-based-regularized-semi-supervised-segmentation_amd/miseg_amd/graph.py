@@ -84,8 +84,8 @@ class StepGraph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=self.stream):
             inter, union = ep._device_step(self.s_li, self.s_lt, self.s_ui, self.s_masks, seed)
-            self.s_scalars = ep._pending.device_values()
-            names, vals, items = ep._pending.drain()
+            ep._pending.precompute()       # (already done by the guarded optimiser launch unless MISEG_GUARD_STEP=0)
+            names, self.s_scalars, items = ep._pending.take_static()
         self.names, self.items = names, items
         self.s_inter, self.s_union = inter, union
         self.graph, self.key = graph, key

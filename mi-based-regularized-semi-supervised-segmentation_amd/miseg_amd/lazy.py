@@ -136,3 +136,71 @@ def evaluate(items: Sequence[Union[LinearLoss, Tensor]], passthrough: Sequence[T
         if passthrough:
             out = torch.cat([out] + [t.detach().reshape(1).float() for t in passthrough])
         return out
+
+
+_FUSED_REPORT = __import__("os").environ.get("MISEG_FUSED_REPORT", "1") != "0"     # A/B switch: 0 = the torch-op evaluation on the GPU too
+
+
+def report(items: Sequence[Union[LinearLoss, Tensor]], check_items: Sequence[tuple] = ()) -> Tensor:
+    """float32 device vector: the value of every item, then the flag of every deferred check (miseg_amd.checks item tuples), in
+    order -- what ``evaluate(items, passthrough=[flag_tensor(c) ...])`` returns, but on the GPU as (at most) two ``torch.cat`` and
+    ONE launch of ``miseg_report_scalars`` instead of ~20 one-element kernels (isfinite / where / two mat-vecs; isnan-sum-cast per
+    NaN test; a cast per integer flag).  Falls back to ``evaluate`` off the GPU or for flag kinds the kernel does not know."""
+    from . import checks as _checks
+    from ._cabi import call
+    items = [LinearLoss.of(x) for x in items]
+    srcs = [c[0] for c in check_items]
+    tensors_all = [t for it in items for t, _ in it.terms] + [s.tensor if isinstance(s, _checks.LazyFlag) else s for s in srcs if not callable(s) or isinstance(s, _checks.LazyFlag)]
+    fused = bool(tensors_all) and all(torch.is_tensor(t) and t.is_cuda for t in tensors_all) and \
+        all(isinstance(s, _checks.LazyFlag) or (torch.is_tensor(s) and s.dtype == torch.float32) for s in srcs) and \
+        all(s.tensor.dtype == (torch.float32 if s.kind == "nan" else torch.int32) for s in srcs if isinstance(s, _checks.LazyFlag))
+    if not fused or not _FUSED_REPORT:
+        return evaluate(items, passthrough=[_checks.flag_tensor(c) for c in check_items])
+    dev = tensors_all[0].device
+    cur = torch.cuda.current_stream(dev)
+    fl: List[Tensor] = []          # float tensors, in flat order
+    off: Dict[int, int] = {}
+    n_f = 0
+
+    def add_f(t: Tensor) -> int:
+        nonlocal n_f
+        o = off.get(id(t))
+        if o is None:
+            o = off[id(t)] = n_f
+            fl.append(t)
+            n_f += t.numel()
+        return o
+    for it in items:
+        for t, _ in it.terms:
+            add_f(t)
+    C = n_f
+    il: List[Tensor] = []
+    desc: List[int] = []
+    for s in srcs:
+        if isinstance(s, _checks.LazyFlag) and s.kind == "cast":
+            desc += [2, len(il), 0]
+            il.append(s.tensor)
+        elif isinstance(s, _checks.LazyFlag):
+            desc += [1, add_f(s.tensor), s.tensor.numel()]
+        else:
+            desc += [0, add_f(s), 1]
+    for t in fl + il:
+        t.record_stream(cur)          # some were produced on the IIC branch stream
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).float() for t in fl]) if len(fl) > 1 else fl[0].detach().reshape(-1).float()
+        iflat = None if not il else (torch.cat([t.detach().reshape(-1) for t in il]) if len(il) > 1 else il[0].detach().reshape(-1))
+        key = ("rep", str(dev), tuple(tuple((off[id(t)], t.numel(), c) for t, c in it.terms) for it in items), C, tuple(desc))
+
+        def build():
+            m = torch.zeros(max(len(items), 1), max(C, 1), dtype=torch.float32)
+            for r, it in enumerate(items):
+                for t, c in it.terms:
+                    o = off[id(t)]
+                    m[r, o:o + t.numel()] += c
+            d = torch.tensor(desc if desc else [0, 0, 0], dtype=torch.int32)
+            return m.to(dev), d.to(dev)
+        coeff, d_dev = _const(key, build)
+        out = torch.empty(len(items) + len(srcs), dtype=torch.float32, device=dev)
+        call("miseg_report_scalars", cur.cuda_stream, flat.data_ptr(), None if iflat is None else iflat.data_ptr(), coeff.data_ptr(),
+             len(items), C, d_dev.data_ptr(), len(srcs), out.data_ptr())
+    return out

@@ -74,17 +74,27 @@ class _Pending:
         self._names.append(name)
         self._vals.append(value.detach() if isinstance(value, (Tensor, LinearLoss)) else value)
 
-    def guard(self) -> Optional[Tensor]:
-        """The deferred-check flags recorded so far as one fp32 device vector (each lazily recorded flag is evaluated here, once:
-        ``device_values`` reuses the tensors)."""
-        if not self.checks:
-            return None
-        self.checks[:] = [(checks.flag_tensor(c), c[1], c[2]) for c in self.checks]
-        return torch.stack([c[0] for c in self.checks])
+    def precompute(self) -> Optional[Tensor]:
+        """Evaluate everything recorded so far NOW (values and check flags: ``device_values``) and keep the result for the
+        iteration's ``post`` / ``fetch``; returns the check flags (a view of that vector, None without checks) -- the optimiser
+        launch is guarded with them.  Nothing may be ``put`` between this call and the post."""
+        if self._static is None:
+            if not self._vals and not self.checks:
+                return None
+            scalars = self.device_values()
+            self._static = (self._names, scalars, list(self.checks))
+            self._names, self._vals, self.checks[:] = [], [], []
+        names, scalars, items = self._static
+        return scalars[len(names):] if items else None
+
+    def take_static(self):
+        """(names, device vector, check items) of ``precompute`` / ``set_static``, removed."""
+        st, self._static = self._static, None
+        return st
 
     def device_values(self) -> Tensor:
-        """float32 device vector: the put() values followed by the deferred-check flags (one cat + one mat-vec)."""
-        return lazy.evaluate(self._vals, passthrough=[checks.flag_tensor(c) for c in self.checks])
+        """float32 device vector: the put() values followed by the deferred-check flags (one launch: lazy.report)."""
+        return lazy.report(self._vals, self.checks)
 
     def fetch(self) -> dict:
         if self._static is not None:      # values of a replayed step graph: one static device tensor, fixed names and checks
@@ -336,15 +346,17 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             total_loss.backward()
         if self._reducer is not None:
             self._reducer.finish()
-        if hasattr(self._optimizer, "apply"):
-            # the deferred checks recorded so far (simplex / NaN flags of this iteration) guard the update on the device: the host
-            # raises them one iteration late, but a failed one has not moved the weights (the reference raises before backward)
-            self._optimizer.apply(guard=self._pending.guard() if _GUARD_STEP else None)
-        else:
-            self._optimizer.step()
         with torch.no_grad():
             self._pending.put("sup_loss", sup_loss)
             self._pending.put("reg_loss", reg_loss)
+        if hasattr(self._optimizer, "apply"):
+            # The iteration's report (meter values + the simplex / NaN flags) is computed here, in one launch, and its flags guard
+            # the update on the device: the host raises a failed check one iteration late, but it has not moved the weights
+            # (the reference raises before backward).
+            self._optimizer.apply(guard=self._pending.precompute() if _GUARD_STEP else None)
+        else:
+            self._optimizer.step()
+        with torch.no_grad():
             _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False)
         return inter, union
 
