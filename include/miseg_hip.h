@@ -107,6 +107,12 @@ int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S
                          float lamb, float* loss, float* loss_no_lamb, float* joint);
 int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K,
                          float lamb, const float* upstream, float* gx, float* gy);
+/* the same two for the layout the epocher has: prob[S][2N][K] with x = prob[:, :N], y = prob[:, N:] (the two views of the unlabeled
+ * batch, semi_seg/epocher.py:258-262) -- no slice copies forward, ONE gradient tensor gprob[S][2N][K] backward. */
+int miseg_iic_global_fwd_pair(void* stream, const float* prob, int64_t S, int64_t N, int64_t K, float lamb, float* loss,
+                              float* loss_no_lamb, float* joint);
+int miseg_iic_global_bwd_pair(void* stream, const float* prob, int64_t S, int64_t N, int64_t K, float lamb,
+                              const float* upstream, float* gprob);
 
 /* compute_joint on its own (ref iic_loss.py:74-94): joint [S][K][K] = normalised sum_n x_n (x) y_n, symmetrised iff `symmetric`;
  * bwd: gjoint = dL/djoint -> gx, gy [S][N][K]. */

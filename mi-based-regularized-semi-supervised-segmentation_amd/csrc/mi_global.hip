@@ -36,11 +36,11 @@ __device__ void global_joint(const float* x, const float* y, int N, int K, float
 
 __global__ __launch_bounds__(256) void iic_global_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, int N,
                                                              int K, float lamb, float* __restrict__ loss,
-                                                             float* __restrict__ loss_nl, float* __restrict__ joint) {
+                                                             float* __restrict__ loss_nl, float* __restrict__ joint, long long hs) {
     __shared__ float Ps[kMaxK * kMaxK];
     __shared__ float rowv[kMaxK], colv[kMaxK], red[17];
     const int s = blockIdx.x, KK = K * K;
-    global_joint(xs + (size_t)s * N * K, ys + (size_t)s * N * K, N, K, Ps, rowv, colv, red);
+    global_joint(xs + (size_t)s * hs, ys + (size_t)s * hs, N, K, Ps, rowv, colv, red);      // hs: elements between sub-heads
     const float eps = 1e-10f;
     float a = 0.f, b = 0.f;
     for (int e = threadIdx.x; e < KK; e += blockDim.x) {
@@ -59,13 +59,13 @@ __global__ __launch_bounds__(256) void iic_global_fwd_kernel(const float* __rest
 // Gu = d loss / d (unsymmetrised, unnormalised joint) = (Gsym - <Gsym, P>) / Z, Gsym = (Gp + Gp^T)/2.
 __global__ __launch_bounds__(256) void iic_global_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ ys, int N,
                                                              int K, float lamb, const float* __restrict__ upstream,
-                                                             float* __restrict__ gxs, float* __restrict__ gys) {
+                                                             float* __restrict__ gxs, float* __restrict__ gys, long long hs) {
     __shared__ float Ps[kMaxK * kMaxK];
     __shared__ float Gp[kMaxK * kMaxK];
     __shared__ float rowv[kMaxK], colv[kMaxK], red[17];
     const int s = blockIdx.x, KK = K * K;
-    const float* x = xs + (size_t)s * N * K;
-    const float* y = ys + (size_t)s * N * K;
+    const float* x = xs + (size_t)s * hs;
+    const float* y = ys + (size_t)s * hs;
     global_joint(x, y, N, K, Ps, rowv, colv, red);
     // recover Z (sum of the symmetrised raw joint) = sum_n (sum_i x)(sum_j y)
     float z = 0.f;
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void iic_global_bwd_kernel(const float* __rest
             ax += Ps[k * K + t] * y[n * K + t];
             ay += Ps[t * K + k] * x[n * K + t];
         }
-        gxs[(size_t)s * N * K + e] = ax;
-        gys[(size_t)s * N * K + e] = ay;
+        gxs[(size_t)s * hs + e] = ax;
+        gys[(size_t)s * hs + e] = ay;
     }
 }
 
@@ -309,12 +309,32 @@ extern "C" int miseg_iic_global_joint_bwd(void* stream, const float* x, const fl
     return MISEG_OK;
 }
 
+extern "C" int miseg_iic_global_fwd_pair(void* stream, const float* prob, int64_t S, int64_t N, int64_t K, float lamb, float* loss,
+                                         float* loss_no_lamb, float* joint) {
+    MISEG_REQUIRE(prob && loss && loss_no_lamb && joint, "iic_global_fwd: null pointer");
+    MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_fwd: need 0<K<=%d", kMaxK);
+    hipLaunchKernelGGL(iic_global_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), prob, prob + N * K, (int)N, (int)K, lamb, loss,
+                       loss_no_lamb, joint, (long long)(2 * N * K));
+    MISEG_LAUNCH_CHECK("iic_global_fwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_global_bwd_pair(void* stream, const float* prob, int64_t S, int64_t N, int64_t K, float lamb, const float* upstream,
+                                         float* gprob) {
+    MISEG_REQUIRE(prob && gprob, "iic_global_bwd: null pointer");
+    MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_bwd: need 0<K<=%d", kMaxK);
+    hipLaunchKernelGGL(iic_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), prob, prob + N * K, (int)N, (int)K, lamb,
+                       upstream, gprob, gprob + N * K, (long long)(2 * N * K));
+    MISEG_LAUNCH_CHECK("iic_global_bwd_kernel");
+    return MISEG_OK;
+}
+
 extern "C" int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, float lamb,
                                     float* loss, float* loss_no_lamb, float* joint) {
     MISEG_REQUIRE(x && y && loss && loss_no_lamb && joint, "iic_global_fwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_fwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_global_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, lamb, loss,
-                       loss_no_lamb, joint);
+                       loss_no_lamb, joint, (long long)(N * K));
     MISEG_LAUNCH_CHECK("iic_global_fwd_kernel");
     return MISEG_OK;
 }
@@ -324,7 +344,7 @@ extern "C" int miseg_iic_global_bwd(void* stream, const float* x, const float* y
     MISEG_REQUIRE(x && y && gx && gy, "iic_global_bwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_bwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, lamb,
-                       upstream, gx, gy);
+                       upstream, gx, gy, (long long)(N * K));
     MISEG_LAUNCH_CHECK("iic_global_bwd_kernel");
     return MISEG_OK;
 }

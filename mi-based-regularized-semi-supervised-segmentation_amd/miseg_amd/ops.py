@@ -292,6 +292,41 @@ def global_mi(x: Tensor, y: Tensor, lamb: float = 1.0):
     return _GlobalMI.apply(x, y, float(lamb))
 
 
+class _GlobalMIPair(torch.autograd.Function):
+    """IIDLoss for S sub-heads on prob[S, 2N, K] = [view 1 | view 2] along dim 1 (the layout the heads produce): the kernels read the
+    two halves in place and write ONE gradient tensor -- no slice copies, no zero-filled halves added together by autograd."""
+
+    @staticmethod
+    def forward(ctx, prob: Tensor, lamb: float):
+        _need_gpu(prob)
+        prob = prob.contiguous().float()
+        s, n2, k = prob.shape
+        n = n2 // 2
+        loss = torch.empty(s, dtype=torch.float32, device=prob.device)
+        loss_nl = torch.empty_like(loss)
+        joint = torch.empty(s, k, k, dtype=torch.float32, device=prob.device)
+        call("miseg_iic_global_fwd_pair", _stream(), _ptr(prob), s, n, k, float(lamb), _ptr(loss), _ptr(loss_nl), _ptr(joint))
+        ctx.save_for_backward(prob)
+        ctx.lamb = float(lamb)
+        ctx.mark_non_differentiable(loss_nl, joint)
+        return loss, loss_nl, joint
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g2):
+        prob, = ctx.saved_tensors
+        s, n2, k = prob.shape
+        gprob = torch.empty_like(prob)
+        call("miseg_iic_global_bwd_pair", _stream(), _ptr(prob), s, n2 // 2, k, ctx.lamb, _ptr(gloss.contiguous().float()), _ptr(gprob))
+        return gprob, None
+
+
+def global_mi_pair(prob: Tensor, lamb: float = 1.0):
+    """(loss[S], loss_no_lamb[S], joint[S,K,K]) of IIDLoss(prob[:, :N], prob[:, N:]) for prob[S, 2N, K]."""
+    if prob.shape[1] % 2:
+        raise _cabi.MisegError(f"global_mi_pair: prob holds {prob.shape[1]} rows per sub-head, expected an even number (two views)")
+    return _GlobalMIPair.apply(prob, float(lamb))
+
+
 class _GlobalJoint(torch.autograd.Function):
     """compute_joint (ref iic_loss.py:74-94) for S pairs at once: x, y [S,N,K] -> joint [S,K,K]."""
 

@@ -530,7 +530,9 @@ class IICTrainEpocher(TrainEpocher):
             if _DEBUG_ASSERTS:
                 from contrastyou.losses.iic_loss import simplex
                 assert simplex(probs.flatten(0, 1))
-            per_head, _, _ = ops.global_mi(probs[:, :ub], probs[:, ub:], criterion.lamb)
+            if probs.shape[1] != 2 * ub:
+                raise RuntimeError(f"encoder tap: {probs.shape[1]} rows per sub-head, expected 2 x {ub}")
+            per_head, _, _ = ops.global_mi_pair(probs, criterion.lamb)
             return LinearLoss.mean(per_head)
         # decoder tap: replay the flip on features(unlabeled) (ref :264-266), fused into the head
         probs = projector.forward_gathered(feature, src, flips2)  # [S, 2UB, K, H, W]

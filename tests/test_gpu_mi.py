@@ -195,6 +195,25 @@ def test_global_mi(golden, n, k):
     assert float(xs.grad[1].abs().max()) == 0.0   # untouched sub-heads get exactly zero
 
 
+@pytest.mark.parametrize("n,k", [(7, 5), (16, 20)])
+def test_global_mi_pair_is_bitwise_the_two_tensor_form(n, k):
+    """`global_mi_pair(prob[S, 2N, K])` (the epocher's layout: the two views stacked along dim 1, read in place, ONE gradient
+    tensor) against `global_mi(prob[:, :N], prob[:, N:])` (pinned to the golden vectors above): same kernels, same order of
+    operations -> identical bits for losses, joints and gradients."""
+    prob = T(synth.probs(f"gpair_n{n}_k{k}", (3 * 2 * n, k))).view(3, 2 * n, k).to(DEV)
+    wts = torch.tensor([1.0, -2.0, 0.5], device=DEV)
+    a = prob.clone().requires_grad_(True)
+    la, la_nl, ja = ops().global_mi_pair(a)
+    (la * wts).sum().backward()
+    b = prob.clone().requires_grad_(True)
+    lb, lb_nl, jb = ops().global_mi(b[:, :n], b[:, n:])
+    (lb * wts).sum().backward()
+    assert torch.equal(la, lb) and torch.equal(la_nl, lb_nl) and torch.equal(ja, jb)
+    assert torch.equal(a.grad, b.grad)
+    with pytest.raises(Exception):
+        ops().global_mi_pair(prob[:, :2 * n - 1])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_local_head_fwd_bwd(golden, dtype):
     """LocalClusterHead (linear) incl. the fused sample gather + flip replay, vs oracle autograd."""
