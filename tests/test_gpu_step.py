@@ -326,9 +326,10 @@ def test_deferred_readback_records_every_iteration_like_the_synchronous_one():
         ep.run()
     # the failed check is raised one iteration late, but it guarded the Adam launches on the device: no weight has moved -- the state
     # the reference, which raises before backward (iic_loss.py:147-148), leaves behind.  (NaN-free part of the buffer: the poisoned bias.)
-    now = opt.flat.flat_param.detach()
-    keep = ~torch.isnan(snap)
-    assert torch.equal(now[keep], snap[keep]) and bool(torch.isnan(now[~keep]).all())
+    if os.environ.get("MISEG_GUARD_STEP", "1") != "0":
+        now = opt.flat.flat_param.detach()
+        keep = ~torch.isnan(snap)
+        assert torch.equal(now[keep], snap[keep]) and bool(torch.isnan(now[~keep]).all())
 
 
 def test_step_graph_replay_equals_eager_steps():
