@@ -117,3 +117,27 @@ def test_run_directory_matches_the_reference_trainers(golden, tmp_path, name):
     assert rows[0].split(",") == [str(x) for x in g[f"{name}/csv_header"]]
     assert [r.split(",")[0] for r in rows[1:]] == [str(x) for x in g[f"{name}/csv_index"]]
     assert [f"{k}={type(v).__name__}" for k, v in ck["_buffers"].items()] == [str(x) for x in g[f"{name}/buffers"]]
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the driver's fields (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload), the `roofline` object of the dominant kernel measured
+    with HIP events inside the timed region, and -- through `--gpus 1 --spawn`-style self-launch -- the rank count the process group saw."""
+    import json
+    res = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "rccl_ranks", "backend"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["dtype"] == "bf16" and d["scaling"] == "weak"
+    assert d["unit"] == "images/s" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]            # value = images of the timed steps / time
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms", "ceiling_frac", "sustained_peak"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["kernel"].startswith("iic_local_bwd") and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 0.5 and r["avg_ms"] < d["ms_per_step"]
