@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                      int M, const float* __restrict__ w, int S, float invT,
                                                                      const float* __restrict__ prob, const float* __restrict__ gprob,
-                                                                     bf16* __restrict__ gfeat, float* __restrict__ partials) {
+                                                                     bf16* __restrict__ gfeat, float* __restrict__ partials, int accumulate) {
     constexpr int K = 20, SM = 5, CT = C / 16, AR = 24, BR = 72;
     constexpr int WAVE_LDS = (2 * 64 * AR + 2 * K * BR + C * BR) * 2;   // bytes per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char hb[];
@@ -908,8 +908,14 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         s16x4 o;
+                        if (accumulate) {      // gfeat already holds another consumer's gradient of the same feature: add, round once
+                            const s16x4 old = *reinterpret_cast<const s16x4*>(gp + ct * 16 + 4 * q);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16_bits(agf[t][ct][r]);
+                            for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16_bits(agf[t][ct][r] + bf16_bits_to_f32((unsigned short)old[r]));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16_bits(agf[t][ct][r]);
+                        }
                         *reinterpret_cast<s16x4*>(gp + ct * 16 + 4 * q) = o;
                     }
                 }
@@ -1020,11 +1026,36 @@ extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W
     return (((int64_t)head_w_blocks(M, H * W) + 1) * (S * K * C + S * K)) * 4;
 }
 
+static bool head_bwd_wave_shape(int dt, int64_t C, int64_t S, int64_t K) { return dt == MISEG_BF16 && K == 20 && C == 16 && S == 5 && !head_bwd_wave_off(); }
+
+extern "C" int64_t miseg_head_local_bwd_acc_supported(int dt, int64_t C, int64_t S, int64_t K) {
+    return head_bwd_wave_shape(dt == MISEG_F16 ? MISEG_BF16 : dt, C, S, K);
+}
+
+static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
+                               const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K, float T, const float* prob,
+                               const float* gprob, void* gfeat, float* gw, float* gb, void* ws, int64_t ws_bytes, int accumulate);
+
 extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
                                     float T, const float* prob, const float* gprob, void* gfeat, float* gw, float* gb, void* ws,
                                     int64_t ws_bytes) {
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes);
+    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes, 0);
+}
+
+extern "C" int miseg_head_local_bwd_acc(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                        const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
+                                        float T, const float* prob, const float* gprob, void* gfeat_inout, float* gw, float* gb, void* ws,
+                                        int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd_acc, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes);
+    MISEG_REQUIRE(gfeat_inout && head_bwd_wave_shape(dt, C, S, K), "head_local_bwd_acc: shape not supported (ask miseg_head_local_bwd_acc_supported)");
+    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes, 1);
+}
+
+static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
+                               const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K, float T, const float* prob,
+                               const float* gprob, void* gfeat, float* gw, float* gb, void* ws, int64_t ws_bytes, int accumulate) {
     MISEG_REQUIRE(feat && src && w && prob && gprob && gw && gb && ws, "head_local_bwd: null pointer");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 128 && K > 0 && K <= 64 && S * K <= 256 && M > 0, "head_local_bwd: need C%%4==0, C<=128, S*K<=256");
     MISEG_REQUIRE(ws_bytes >= miseg_head_local_bwd_ws_bytes(M, H, W, C, S, K), "head_local_bwd: workspace too small");
@@ -1039,7 +1070,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
         lds = std::max(lds, ((size_t)2 * 128 * 72 + cp * 72 + 2 * cp * 136) * 2 + (size_t)4 * 5 * 64 * 4);
     }
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
-    if (dt == MISEG_BF16 && K == 20 && C == 16 && S == 5 && !head_bwd_wave_off()) {
+    if (head_bwd_wave_shape(dt, C, S, K)) {
         constexpr int wave_lds = (2 * 64 * 24 + 2 * 20 * 72 + 16 * 72) * 2;
         const size_t wl = (size_t)4 * wave_lds + (size_t)S * 2 * 16 * 32 * 2;
         hipFuncSetAttribute((const void*)head_local_bwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
@@ -1050,7 +1081,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
         const int nb = cap > 0 ? std::min(cap, nblk) : nblk;
         nused = nb;   // the final reduction reads this kernel's nb partials only
         hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nb), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
-                           (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials);
+                           (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials, accumulate);
     } else
 #define HLB2(TT, CTM, RW, K20V, BFV)                                                                                                         \
     {                                                                                                                             \

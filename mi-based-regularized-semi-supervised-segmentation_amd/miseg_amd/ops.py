@@ -6,6 +6,7 @@ bookkeeping; all arithmetic happens in ``csrc/*.hip`` behind ``include/miseg_hip
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -292,6 +293,35 @@ def global_mi(x: Tensor, y: Tensor, lamb: float = 1.0):
     return _GlobalMI.apply(x, y, float(lamb))
 
 
+class _GradJoin:
+    """Hand-over of an input gradient between two consumers of ONE feature map, so that autograd has nothing to add.
+
+    The last decoder block's output feeds DeConv_1x1 (the logits) and the local-MI head.  Autograd would add their two 100 MB input
+    gradients with an elementwise kernel on the step's critical path (right after the IIC chain; 45 us alone, up to 150 us beside
+    the next tap's backward).  Instead the consumer whose backward runs first (``conv1x1``: it has its gradient as soon as the
+    supervised / consistency losses are differentiated) ``offer``s the tensor it wrote; the head's backward ``take``s it, makes its
+    stream wait for the writer, ACCUMULATES into it in its kernel epilogue (``miseg_head_local_bwd_acc``), makes the writer's
+    stream wait for that kernel, and returns no gradient of its own.  No offer (another tap, another order, an unsupported shape):
+    the head returns its gradient as before.  ``MISEG_GRAD_JOIN=0`` disables."""
+    enabled = os.environ.get("MISEG_GRAD_JOIN", "1") != "0"
+    _offers: dict = {}
+
+    @classmethod
+    def clear(cls) -> None:
+        cls._offers.clear()
+
+    @classmethod
+    def offer(cls, feature: Tensor, grad: Tensor) -> None:
+        if cls.enabled and feature.is_cuda and grad.shape == feature.shape and grad.dtype == feature.dtype:
+            ev = torch.cuda.Event()
+            ev.record()
+            cls._offers[(feature.data_ptr(), tuple(feature.shape))] = (grad, ev, torch.cuda.current_stream(feature.device))
+
+    @classmethod
+    def take(cls, feature: Tensor):
+        return cls._offers.pop((feature.data_ptr(), tuple(feature.shape)), None) if cls.enabled else None
+
+
 class _GlobalMIPair(torch.autograd.Function):
     """IIDLoss for S sub-heads on prob[S, 2N, K] = [view 1 | view 2] along dim 1 (the layout the heads produce): the kernels read the
     two halves in place and write ONE gradient tensor -- no slice copies, no zero-filled halves added together by autograd."""
@@ -410,6 +440,26 @@ class _LocalHead(torch.autograd.Function):
         m = src.numel()
         gprob = gprob.contiguous().float()
         gfeat = None
+        joined = None
+        if ctx.needs_input_grad[0] and query("miseg_head_local_bwd_acc_supported", _DT[feat.dtype], c, s, k):
+            joined = _GradJoin.take(feat)
+        if joined is not None:
+            # the other consumer of this feature already wrote its input gradient: add ours to it in the kernel epilogue
+            gsum, written, writer = joined
+            cur = torch.cuda.current_stream(feat.device)
+            cur.wait_event(written)
+            gsum.record_stream(cur)
+            gw = _stacked_grad(ctx.stack_params[0], w.shape, feat.device)
+            gb = _stacked_grad(ctx.stack_params[1], (s, k), feat.device)
+            ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
+            call("miseg_head_local_bwd_acc", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
+                 ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gsum), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
+                 work=(4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 3 * c * feat.element_size()) * m * h * wd), tag=f"head_local_bwd[c{c}]")
+            if writer != cur:
+                done = torch.cuda.Event()
+                done.record(cur)
+                writer.wait_event(done)       # whoever reads the joined gradient next does so on the writer's stream
+            return None, gw, gb, None, None, None
         if ctx.needs_input_grad[0]:
             rng = ctx.src_range
             if rng is not None and feat.dtype in (torch.bfloat16, torch.float16) and k == 20 and s == 5 and c in (16, 32) and 0 <= rng[0] <= rng[1] <= bsz:

@@ -332,6 +332,8 @@ class _Conv1x1(torch.autograd.Function):
         bf = bias.contiguous().float()
         out = empty_nhwc(n, cout, h, w, torch.float32, x.device)
         call("miseg_conv1x1_fwd", _stream(), _DT[x.dtype], _ptr(x), n, h, w, cin, _ptr(wf), _ptr(bf), cout, _ptr(out))
+        from .ops import _GradJoin
+        _GradJoin.clear()                # offers of an earlier backward pass that nobody took
         ctx.save_for_backward(x, wf)
         ctx.wshape = tuple(weight.shape)
         return out
@@ -348,6 +350,9 @@ class _Conv1x1(torch.autograd.Function):
         ws = _ws(query("miseg_conv1x1_bwd_ws_bytes", n, h, w, cin, cout), x.device)
         call("miseg_conv1x1_bwd", _stream(), _DT[x.dtype], _ptr(x), _ptr(gout), n, h, w, cin, _ptr(wf), cout, _ptr(gin), _ptr(gw), _ptr(gb),
              _ptr(ws), ws.numel())
+        if gin is not None:
+            from .ops import _GradJoin
+            _GradJoin.offer(x, gin)      # a tap's head backward may add its gradient of x into this tensor (ops._GradJoin)
         return gin, gw.view(ctx.wshape), gb
 
 

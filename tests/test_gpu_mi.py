@@ -437,6 +437,44 @@ def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch, s, ub):
             assert abs(float(per_window[0, wi]) - float(truth)) <= 5e-7, (wi, float(per_window[0, wi]), float(truth))
 
 
+@pytest.mark.parametrize("h,w", [(64, 64), (37, 45)])
+def test_head_backward_joins_an_offered_gradient(h, w):
+    """ops._GradJoin: when another consumer of the tapped feature (DeConv_1x1) has offered the input gradient it wrote, the head's
+    backward adds its own into that tensor in the kernel epilogue (`miseg_head_local_bwd_acc`) and returns none -- autograd then has
+    nothing to add.  Result = offered + the head's stand-alone gradient up to ONE bf16 rounding of the sum (the two-kernel form rounds
+    twice); rows outside the gathered range keep the offered values bit for bit; weight gradients are unchanged."""
+    from miseg_amd import ops as O
+    bsz, c, s, k = 6, 16, 5, 20
+    feat = T(synth.normal(f"join/{h}/f", (bsz, c, h, w))).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = T(synth.normal(f"join/{h}/w", (s, k, c), scale=0.3)).to(DEV)
+    bs = T(synth.normal(f"join/{h}/b", (s, k), scale=0.1)).to(DEV)
+    src = O.arange_i32(2, 6, DEV)
+    flips = torch.tensor([0, 1, 2, 3], dtype=torch.int32, device=DEV)
+    cot = T(synth.normal(f"join/{h}/cot", (s, 4, k, h, w))).to(DEV)
+    base = T(synth.normal(f"join/{h}/g0", (bsz, c, h, w))).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(offer):
+        f = feat.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        w_, b_ = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+        prob = O.local_head(f, w_, b_, src, flips, 1.0)
+        O._GradJoin.clear()
+        g0 = base.clone(memory_format=torch.preserve_format)
+        if offer:
+            O._GradJoin.offer(f.detach(), g0)
+        (prob * cot).sum().backward()
+        return f.grad, g0, w_.grad, b_.grad
+
+    g_alone, _, gw_a, gb_a = run(False)
+    g_none, g_joined, gw_j, gb_j = run(True)
+    assert g_none is None and not O._GradJoin._offers
+    ref = base.float() + g_alone.float()
+    assert torch.equal(g_joined[:2], base[:2])                                        # rows that are not gathered: untouched
+    err = (g_joined.float() - ref).abs()
+    bound = 2.0 ** -8 * (base.float().abs() + 2 * g_alone.float().abs()) + 1e-6        # rounding of the sum + the bf16 rounding of g_alone itself
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert torch.equal(gw_a, gw_j) and torch.equal(gb_a, gb_j)
+
+
 @pytest.mark.parametrize("c,h,w", [(32, 40, 48), (16, 6, 10), (16, 72, 36)])
 def test_local_head_forward_mfma_vs_float64(c, h, w):
     """The shipped taps (bf16 features, S=5 x K=20, C in {16, 32}) compute the logits on the matrix pipe with the fp32
