@@ -268,6 +268,11 @@ int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups
 int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout);
 int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
                               const void* packed_w, int64_t Cout, void* out_pooled);
+/* ... ADDING to inout_pooled instead of storing: the pre-upsample feature is also a local-MI tap whose head backward has already
+ * written its gradient there (ops._GradJoin) -- replaces autograd's add of the two.  Streaming shapes only. */
+int64_t miseg_conv3x3_fwd_sumpool_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
+int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
+                                  const void* packed_w, int64_t Cout, void* inout_pooled);
 /* conv3x3_fwd + bn_finalize in ONE launch (training mode): the block that finishes last sums the partial rows and writes
  * `saved` / the running statistics itself (same formulas as miseg_bn_finalize; the sums are combined in a different but fixed
  * order).  sync_counter: one int32 in device memory, 0 on entry, 0 again when the kernel ends -- the caller may hand the same

@@ -194,6 +194,7 @@ struct BnFinish {
     unsigned int* counter;           // null: the caller launches bn_finalize_kernel itself
     const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt; float* saved;
     float count, eps, momentum;
+    int accumulate_out;              // POOL epilogues of the conv kernels: add to the output tensor instead of storing (a gradient join)
 };
 __device__ __forceinline__ void bn_finish_block(const float* __restrict__ parts, int nparts, int C, const BnFinish& f, float* lds) {
     const float* sums = block_column_sums(parts, nparts, 2 * C, lds);      // [sum | sum of squares] per channel

@@ -357,7 +357,12 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
                 T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout + co0 + kq * 4;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (co0 + t * 16 + kq * 4 + 4 <= Cout) *reinterpret_cast<uint2*>(op + t * 16) = pk[mp][t];
+                    if (fin.accumulate_out) {   // the output already holds another consumer's gradient of this tensor (ops._GradJoin)
+                        const T* e = reinterpret_cast<const T*>(&pk[mp][t]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + t * 16 + kq * 4 + r < Cout) op[t * 16 + r] = from_f32<T>(to_f32(op[t * 16 + r]) + to_f32(e[r]));
+                    } else if (co0 + t * 16 + kq * 4 + 4 <= Cout) *reinterpret_cast<uint2*>(op + t * 16) = pk[mp][t];
                     else {
                         const T* e = reinterpret_cast<const T*>(&pk[mp][t]);
 #pragma unroll
@@ -1144,6 +1149,19 @@ extern "C" int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, i
                                          const void* packed_w, int64_t Cout, void* out_pooled) {
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_sumpool, stream, MISEG_BF16, in, Cin, N, H, W, packed_w, Cout, out_pooled);
     return conv3x3_fwd_impl(stream, dt, in, Cin, 0, nullptr, 0, 0, N, H, W, packed_w, Cout, out_pooled, nullptr, BnFinish{}, true);
+}
+
+extern "C" int64_t miseg_conv3x3_fwd_sumpool_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
+    return conv_streams(dt == MISEG_F16 ? MISEG_BF16 : dt, Cin, N, H, W) && H % 2 == 0 && W % 2 == 0;
+}
+
+extern "C" int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
+                                             const void* packed_w, int64_t Cout, void* inout_pooled) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_sumpool_acc, stream, MISEG_BF16, in, Cin, N, H, W, packed_w, Cout, inout_pooled);
+    MISEG_REQUIRE(miseg_conv3x3_fwd_sumpool_acc_supported(dt, Cin, N, H, W), "conv3x3_fwd_sumpool_acc: streaming shapes only");
+    BnFinish opt{};
+    opt.accumulate_out = 1;
+    return conv3x3_fwd_impl(stream, dt, in, Cin, 0, nullptr, 0, 0, N, H, W, packed_w, Cout, inout_pooled, nullptr, opt, true);
 }
 
 // The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.

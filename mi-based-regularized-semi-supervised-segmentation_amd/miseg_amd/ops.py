@@ -302,7 +302,9 @@ class _GradJoin:
     supervised / consistency losses are differentiated) ``offer``s the tensor it wrote; the head's backward ``take``s it, makes its
     stream wait for the writer, ACCUMULATES into it in its kernel epilogue (``miseg_head_local_bwd_acc``), makes the writer's
     stream wait for that kernel, and returns no gradient of its own.  No offer (another tap, another order, an unsupported shape):
-    the head returns its gradient as before.  ``MISEG_GRAD_JOIN=0`` disables."""
+    the head returns its gradient as before.  The protocol is symmetric -- whoever runs first returns its tensor to autograd AND
+    offers it, whoever runs second and can accumulate takes it and returns None: at the 32-channel tap the head runs first and
+    ``up_conv``'s pooled data gradient (``miseg_conv3x3_fwd_sumpool_acc``) is the one that adds.  ``MISEG_GRAD_JOIN=0`` disables."""
     enabled = os.environ.get("MISEG_GRAD_JOIN", "1") != "0"
     _offers: dict = {}
 
@@ -478,6 +480,8 @@ class _LocalHead(torch.autograd.Function):
         call("miseg_head_local_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
              ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
              work=(4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 2 * c * feat.element_size()) * m * h * wd), tag=f"head_local_bwd[c{c}]")
+        if gfeat is not None:
+            _GradJoin.offer(feat, gfeat)     # a later consumer of the same feature (e.g. up_conv's pooled data gradient) may add into it
         return gfeat, gw, gb, None, None, None
 
 

@@ -297,6 +297,23 @@ class _ConvBNReLU(torch.autograd.Function):
             if ups and _FUSE_UPS_DGRAD and query("miseg_conv3x3_fwd_sumpool_supported", _DT[dtype], cout, n, h, w, cs):
                 # the source was read through the x2 upsample: its gradient is the 2x2 sum-pool of the data gradient -- pooled in the
                 # convolution's epilogue, the full-resolution gradient (4x the bytes) never exists
+                from .ops import _GradJoin
+                joined = _GradJoin.take(xs) if query("miseg_conv3x3_fwd_sumpool_acc_supported", _DT[dtype], cout, n, h, w) else None
+                if joined is not None:
+                    # the source is also a local-MI tap and its head's backward has already written its gradient: add ours into it
+                    gsum, written, writer = joined
+                    cur_s = torch.cuda.current_stream(dev)
+                    cur_s.wait_event(written)
+                    gsum.record_stream(cur_s)
+                    call("miseg_conv3x3_fwd_sumpool_acc", _stream(), _DT[dtype], _ptr(graw), cout, n, h, w, _ptr(packed), cs, _ptr(gsum),
+                         work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs / 2 + cout)),
+                         tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+                    if writer != cur_s:
+                        done = torch.cuda.Event()
+                        done.record(cur_s)
+                        writer.wait_event(done)
+                    grads[s] = None
+                    continue
                 glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
                 call("miseg_conv3x3_fwd_sumpool", _stream(), _DT[dtype], _ptr(graw), cout, n, h, w, _ptr(packed), cs, _ptr(glow),
                      work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs / 4 + cout)),
