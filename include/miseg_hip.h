@@ -148,7 +148,7 @@ int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int6
                          float* gb, void* ws, int64_t ws_bytes);
 /* the same, ADDING to gfeat_inout in place of storing (rows of src only; one rounding of the sum): for a tapped feature whose other
  * consumer -- DeConv_1x1 at the last decoder block, unet.py:84,129 -- has already written its input gradient there, so that autograd
- * has nothing left to add (a 300 MB elementwise pass on the step's critical path).  The shipped tap shape only: ask _supported. */
+ * has nothing left to add (a 300 MB elementwise pass on the step's critical path). */
 int64_t miseg_head_local_bwd_acc_supported(int dt, int64_t C, int64_t S, int64_t K);
 int miseg_head_local_bwd_acc(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                              const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
                                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
                                                                    int M, const float* __restrict__ w, int S, int K, float invT,
                                                                    const float* __restrict__ prob, const float* __restrict__ gprob,
-                                                                   T* __restrict__ gfeat, float* __restrict__ partials, int nblk) {
+                                                                   T* __restrict__ gfeat, float* __restrict__ partials, int nblk, int accumulate) {
     extern __shared__ float sm[];
     const int R = S * K, RT = (R + 15) / 16, RP = RT * 16, CT = (C + 15) / 16, HW = H * W;
     constexpr int DZS = 65;
@@ -653,7 +653,11 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
 #pragma unroll
                 for (int c = 0; c < CTM; ++c) {
                     const int cc = c * 16 + kq * 4;
-                    if (c < CT && cc + 3 < C) {
+                    if (c < CT && accumulate) {      // gfeat holds another consumer's gradient of the feature (ops._GradJoin): add, round once
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (cc + r < C) gp[cc + r] = from_f32<T>(accf[c][r] + to_f32(gp[cc + r]));
+                    } else if (c < CT && cc + 3 < C) {
                         T pk[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(accf[c][r]);
@@ -1029,7 +1033,8 @@ extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W
 static bool head_bwd_wave_shape(int dt, int64_t C, int64_t S, int64_t K) { return dt == MISEG_BF16 && K == 20 && C == 16 && S == 5 && !head_bwd_wave_off(); }
 
 extern "C" int64_t miseg_head_local_bwd_acc_supported(int dt, int64_t C, int64_t S, int64_t K) {
-    return head_bwd_wave_shape(dt == MISEG_F16 ? MISEG_BF16 : dt, C, S, K);
+    (void)dt; (void)S; (void)K;
+    return C % 4 == 0;      // every kernel behind miseg_head_local_bwd has the accumulating store (each gfeat element has one writer)
 }
 
 static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
@@ -1049,7 +1054,7 @@ extern "C" int miseg_head_local_bwd_acc(void* stream, int dt, const void* feat, 
                                         float T, const float* prob, const float* gprob, void* gfeat_inout, float* gw, float* gb, void* ws,
                                         int64_t ws_bytes) {
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd_acc, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes);
-    MISEG_REQUIRE(gfeat_inout && head_bwd_wave_shape(dt, C, S, K), "head_local_bwd_acc: shape not supported (ask miseg_head_local_bwd_acc_supported)");
+    MISEG_REQUIRE(gfeat_inout, "head_local_bwd_acc: null gradient tensor");
     return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes, 1);
 }
 
@@ -1087,7 +1092,7 @@ static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B
     {                                                                                                                             \
         hipFuncSetAttribute((const void*)head_local_bwd_fused_kernel<TT, CTM, RW, K20V, BFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((head_local_bwd_fused_kernel<TT, CTM, RW, K20V, BFV>), dim3(nblk), dim3(256), lds, st, (const TT*)feat, (int)H, (int)W, (int)C, \
-                           src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk);            \
+                           src, flips, (int)M, w, (int)S, (int)K, 1.0f / T, prob, gprob, (TT*)gfeat, partials, nblk, accumulate); \
     }
 #define HLB(TT, CTM) { if (K == 20 && R <= 100 && sizeof(TT) == 2 && CTM == 2 && C == 32) HLB2(TT, CTM, 25, true, true)   /* 16 channels: HBM-bound either way and the bf16 variant does not fit 3 blocks per CU */ else if (K == 20 && R <= 100) HLB2(TT, CTM, 25, true, false) else if (R <= 112) HLB2(TT, CTM, 28, false, false) else HLB2(TT, CTM, 64, false, false) }
 #define HLB_C(TT) { if (C <= 16) HLB(TT, 1) else if (C <= 32) HLB(TT, 2) else if (C <= 64) HLB(TT, 4) else HLB(TT, 8) }

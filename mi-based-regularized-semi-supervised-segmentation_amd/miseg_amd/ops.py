@@ -314,7 +314,13 @@ class _GradJoin:
 
     @classmethod
     def offer(cls, feature: Tensor, grad: Tensor) -> None:
+        """Only inside a backward pass; the offers die with it (a storage address may be another tensor's in the next pass)."""
         if cls.enabled and feature.is_cuda and grad.shape == feature.shape and grad.dtype == feature.dtype:
+            if not cls._offers:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(cls.clear)
+                except RuntimeError:      # not called from a backward pass: no hand-over
+                    return
             ev = torch.cuda.Event()
             ev.record()
             cls._offers[(feature.data_ptr(), tuple(feature.shape))] = (grad, ev, torch.cuda.current_stream(feature.device))

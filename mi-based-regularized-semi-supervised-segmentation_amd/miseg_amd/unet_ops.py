@@ -318,6 +318,7 @@ class _ConvBNReLU(torch.autograd.Function):
                 call("miseg_conv3x3_fwd_sumpool", _stream(), _DT[dtype], _ptr(graw), cout, n, h, w, _ptr(packed), cs, _ptr(glow),
                      work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs / 4 + cout)),
                      tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+                _GradJoin.offer(xs, glow)      # if the source is a tap whose head backward has yet to run, it adds into this tensor
                 grads[s] = glow
                 continue
             gfull = empty_nhwc(n, cs, h, w, dtype, dev)

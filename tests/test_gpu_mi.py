@@ -459,8 +459,10 @@ def test_head_backward_joins_an_offered_gradient(h, w):
         prob = O.local_head(f, w_, b_, src, flips, 1.0)
         O._GradJoin.clear()
         g0 = base.clone(memory_format=torch.preserve_format)
-        if offer:
-            O._GradJoin.offer(f.detach(), g0)
+        if offer:      # what a consumer that ran earlier in the same backward pass leaves behind (offer() itself only works inside one)
+            ev = torch.cuda.Event()
+            ev.record()
+            O._GradJoin._offers[(f.data_ptr(), tuple(f.shape))] = (g0, ev, torch.cuda.current_stream())
         (prob * cot).sum().backward()
         return f.grad, g0, w_.grad, b_.grad
 
