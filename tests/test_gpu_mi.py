@@ -664,3 +664,76 @@ def test_compute_joint_symmetric_switch(symmetric):
     (ref * cot.double()).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(y.grad.cpu().numpy(), y64.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("s,ub,h,w,pad,patch", [(5, 16, 256, 256, 3, 1024), (5, 16, 256, 256, 1, 1024), (2, 1, 512, 512, 3, 128)])
+def test_joint_checksum_at_full_size(s, ub, h, w, pad, patch, precision):
+    """BASELINE full sizes (cfg2: 5 sub-heads x 16 pairs of 20 x 256 x 256 maps, whole-map window, pad 3 and pad 1; cfg4: 512 x 512,
+    49 windows of 128 x 128) through the batched launch the bench uses, checked by a size-independent property: the K probabilities
+    of a pixel sum to one, so the K x K entries of displacement (a, b) must sum to the NUMBER OF PIXEL PAIRS that displacement has
+    inside the window, N (Hw - |a - pad|) (Ww - |b - pad|) -- for every sub-head, window and displacement; and swapping the two
+    views transposes the classes and mirrors the displacement (ref iic_loss.py:120-123: conv2d of x with y as the kernel)."""
+    from miseg_amd import _cabi
+    from contrastyou.losses.iic_loss import _windows
+    k, t = 20, 2 * pad + 1
+    wins = _windows(h, w, (patch, patch), (patch // 2, patch // 2)) if patch < h else [(0, h, 0, w)]
+    P = len(wins)
+    gen = torch.Generator(device="cpu").manual_seed(s * 100 + h + pad)
+    probs = torch.randn(s, 2 * ub, k, h, w, generator=gen).softmax(2).to(DEV)
+    win = torch.tensor(wins, dtype=torch.int32, device=DEV).view(P, 4)
+    prec = {"fp32": 0, "bf16x3": 1}[precision]
+
+    def joint(pr):
+        raw = torch.empty(s, P, t, t, k, k, device=DEV)
+        nb = max(_cabi.query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, P * s), _cabi.query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, P))
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _cabi.call("miseg_iic_local_joint_fwd_heads", torch.cuda.current_stream().cuda_stream, pr.data_ptr(), s, ub, k, h, w, pad, win.data_ptr(), P,
+                   raw.data_ptr(), ws.data_ptr(), ws.numel(), prec)
+        return raw
+    raw = joint(probs)
+    got = raw.double().sum((-1, -2)).cpu()                                   # [S, P, T, T]
+    d = (torch.arange(t) - pad).abs().double()
+    for p_, (h0, h1, w0, w1) in enumerate(wins):
+        want = ub * torch.outer((h1 - h0) - d, (w1 - w0) - d)
+        err = float(((got[:, p_] - want).abs() / want).max())
+        assert err <= 2e-5, (p_, err)
+    # the two views swapped: raw'[a][b][i][j] = raw[T-1-a][T-1-b][j][i]
+    swapped = joint(torch.cat([probs[:, ub:], probs[:, :ub]], 1).contiguous())
+    mirror = raw.flip(2, 3).transpose(-1, -2)
+    scale = float(raw.abs().max())
+    assert float((swapped - mirror).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("s,ub,h,w,pad,quad", [(5, 16, 256, 256, 3, False), (5, 16, 256, 256, 1, False), (3, 4, 256, 256, 3, True)])
+def test_backward_neighbour_count_at_full_size(s, ub, h, w, pad, quad, precision):
+    """The local-MI backward at BASELINE cfg2's full size through the batched launch, checked by a closed form: with dLoss/draw = 1
+    everywhere the gradient of a probability is the sum over the displacement window of the OTHER view's class sum = the number of
+    in-window neighbours, cnt(row) x cnt(col), identical for every class, sample and sub-head and for both views -- which walks every
+    boundary of the kernel's work split (strip edges, the run boundaries between waves and blocks, window edges).  `quad`: four
+    non-overlapping 128 x 128 windows in one launch."""
+    from miseg_amd import _cabi
+    k, t = 20, 2 * pad + 1
+    wins = [(0, 128, 0, 128), (0, 128, 128, 256), (128, 256, 0, 128), (128, 256, 128, 256)] if quad else [(0, h, 0, w)]
+    P = len(wins)
+    gen = torch.Generator(device="cpu").manual_seed(s * 10 + pad)
+    probs = torch.randn(s, 2 * ub, k, h, w, generator=gen).softmax(2).to(DEV)
+    win = torch.tensor(wins, dtype=torch.int32, device=DEV).view(P, 4)
+    graw = torch.ones(s, P, t, t, k, k, device=DEV)
+    scale = torch.full((s, P), 0.5, device=DEV)
+    gprob = torch.full_like(probs, float("nan"))
+    nb = _cabi.query("miseg_iic_local_bwd_ws_bytes", k, pad, P * s)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _cabi.call("miseg_iic_local_bwd_heads", torch.cuda.current_stream().cuda_stream, probs.data_ptr(), s, ub, k, h, w, pad, win.data_ptr(), P,
+               graw.data_ptr(), scale.data_ptr(), gprob.data_ptr(), 0, {"fp32": 0, "bf16x3": 1}[precision], ws.data_ptr(), ws.numel())
+    want = torch.zeros(h, w, dtype=torch.float64)
+    for h0, h1, w0, w1 in wins:
+        r, c = torch.arange(h0, h1), torch.arange(w0, w1)
+        cr = (torch.minimum(r + pad, torch.tensor(h1 - 1)) - torch.maximum(r - pad, torch.tensor(h0)) + 1).double()
+        cc = (torch.minimum(c + pad, torch.tensor(w1 - 1)) - torch.maximum(c - pad, torch.tensor(w0)) + 1).double()
+        want[h0:h1, w0:w1] = 0.5 * torch.outer(cr, cc)
+    got = gprob.double().cpu()
+    assert bool(torch.isfinite(got).all())
+    err = ((got - want) .abs() / want).amax()
+    assert float(err) <= 2e-5, float(err)
