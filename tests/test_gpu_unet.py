@@ -300,3 +300,44 @@ def test_upsampled_source_gradient_pooled_in_the_dgrad_epilogue(shape, dtype, mo
     assert float((fused - two).abs().max()) <= 4 * ulp * scale
     e_fused, e_two = float((fused - xr.grad).abs().mean()), float((two - xr.grad).abs().mean())
     assert e_fused <= 1.05 * e_two + 1e-9, (e_fused, e_two)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("n,h,w,cin,cout", [(48, 256, 256, 16, 16), (48, 128, 128, 32, 32), (48, 64, 64, 64, 64), (48, 16, 16, 256, 256), (5, 250, 230, 24, 32)])
+def test_conv3x3_exact_properties_at_full_size(n, h, w, cin, cout, dtype):
+    """The convolution entry points at the bench's full layer sizes (streaming and tiled kernels, every storage type), checked by
+    properties that hold EXACTLY: (a) a centre-tap identity kernel returns the input bit for bit; (b) all-ones weights on an all-ones
+    input give (valid taps) x Cin at every pixel -- 9 Cin inside, 6 Cin on edges, 4 Cin in corners (zero padding, ref unet.py:15);
+    (c) the pooled-output form (`miseg_conv3x3_fwd_sumpool`, where supported) gives the 2 x 2 sums of (b)."""
+    from miseg_amd import _cabi, unet_ops
+    from miseg_amd.ops import _DT
+    dt = _DT[dtype]
+    st = torch.cuda.current_stream().cuda_stream
+    x = nhwc(T(synth.normal(f"convprop/{n}/{h}/{cin}", (n, cin, h, w))).to(DEV).to(dtype))
+    # (a) identity
+    if cin == cout:
+        wid = torch.zeros(cout, cin, 3, 3, device=DEV)
+        wid[torch.arange(cout), torch.arange(cin), 1, 1] = 1.0
+        out = torch.empty_like(x)
+        _cabi.call("miseg_conv3x3_fwd", st, dt, x.data_ptr(), cin, 0, None, 0, 0, n, h, w, unet_ops._pack_now(wid, dtype, 0, 0, cin).data_ptr(), cout,
+                   out.data_ptr(), None)
+        assert torch.equal(out, x)
+    # (b) tap counts
+    ones = nhwc(torch.ones(n, cin, h, w, device=DEV, dtype=dtype))
+    wone = torch.ones(cout, cin, 3, 3, device=DEV)
+    packed = unet_ops._pack_now(wone, dtype, 0, 0, cin)
+    out = nhwc(torch.empty(n, cout, h, w, device=DEV, dtype=dtype))
+    _cabi.call("miseg_conv3x3_fwd", st, dt, ones.data_ptr(), cin, 0, None, 0, 0, n, h, w, packed.data_ptr(), cout, out.data_ptr(), None)
+    r = torch.full((h,), 3.0); r[0] = r[-1] = 2.0
+    c = torch.full((w,), 3.0); c[0] = c[-1] = 2.0
+    taps = (torch.outer(r, c) * cin).to(DEV)
+    assert torch.equal(out.float(), taps.expand(n, cout, h, w))                     # integers <= 2304: exact in bf16 / half / fp32 sums
+    # (c) pooled output
+    if dtype != torch.float32 and _cabi.query("miseg_conv3x3_fwd_sumpool_supported", dt, cin, n, h, w, cout):
+        pooled = nhwc(torch.empty(n, cout, h // 2, w // 2, device=DEV, dtype=dtype))
+        _cabi.call("miseg_conv3x3_fwd_sumpool", st, dt, ones.data_ptr(), cin, n, h, w, packed.data_ptr(), cout, pooled.data_ptr())
+        want = F.avg_pool2d(taps[None, None], 2)[0, 0] * 4
+        if float(want.max()) <= 2048 or dtype == torch.float16 and float(want.max()) <= 2048:
+            assert torch.equal(pooled.float(), want.expand(n, cout, h // 2, w // 2))
+        else:                                                                        # sums above the 16-bit type's exact-integer range: one rounding
+            assert float(((pooled.float() - want) / want).abs().max()) <= 2.0 ** -8
