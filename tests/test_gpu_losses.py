@@ -105,3 +105,49 @@ def test_softmax_kl_consistency_vs_golden_and_flip(golden):
     np.testing.assert_allclose(float(fused), float(ref), rtol=1e-5)
     fused.backward(), ref.backward()
     np.testing.assert_allclose(a2.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_loss_kernels_properties_at_full_size():
+    """The per-pixel loss kernels at BASELINE cfg2's full logits size ([16 | 32, 4, 256, 256]) by size-independent properties:
+    flipping twice is the identity, bit for bit (any payload width); the consistency losses of a map with ITSELF -- through the
+    fused flip replay -- are exactly zero with exactly zero gradient (MSE) / below 1e-7 (KL); `softmax_kl` against its own argmax with
+    sharp logits vanishes; `argmax_dice` of labels that ARE the argmax gives intersection = the class histogram and |pred| + |label| = twice that (Dice exactly 1); a fused Adam
+    step on a zero gradient without weight decay leaves 2.2 M parameters bit-identical, and with weight decay moves each by
+    lr * sign(p) to first order."""
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    n, c, h, w = 16, 4, 256, 256
+    logits = torch.randn(n, c, h, w, generator=gen).to(DEV)
+    dec = OL.flip_decisions(31337, n)
+    fl = ops().flips_to_tensor(dec, DEV)
+    for x in (logits, logits.bfloat16().contiguous(memory_format=torch.channels_last), (logits * 7).long()):
+        assert torch.equal(ops().flip(ops().flip(x, fl), fl), x)
+    # consistency of a map with itself: b = flip(a) replayed with the same flips gives a back
+    a = logits.clone().requires_grad_(True)
+    loss = ops().softmax_mse(a, ops().flip(logits, fl), fl)
+    loss.backward()
+    assert float(loss.detach()) == 0.0 and float(a.grad.abs().max()) == 0.0
+    a2 = logits.clone().requires_grad_(True)
+    kl = ops().softmax_kl_consistency(a2, ops().flip(logits, fl), fl)
+    kl.backward()
+    assert abs(float(kl.detach())) <= 1e-7 and float(a2.grad.abs().max()) <= 1e-9
+    # supervised KL against the own argmax of sharp logits
+    labels = logits.argmax(1)
+    sharp = torch.nn.functional.one_hot(labels, c).permute(0, 3, 1, 2).float().mul(100.0).contiguous()   # softmax = one-hot to 4e-44
+    assert abs(float(ops().softmax_kl(sharp.clone().requires_grad_(True), labels).detach())) <= 1e-6
+    pred, inter, uni = ops().argmax_dice(logits, labels)
+    assert torch.equal(pred, labels)
+    hist = torch.stack([(labels == k).flatten(1).sum(1) for k in range(c)], 1)
+    assert torch.equal(inter, hist) and torch.equal(uni, 2 * hist)      # 'union' = |pred| + |label| (ref general_dice_meter.py:141-172): Dice = 1
+    # fused Adam on the full flat parameter vector
+    from miseg_amd import unet_ops
+    numel = 2_160_180 + 4 * 5 * 20 * 17
+    p0 = torch.randn(numel, generator=gen).to(DEV)
+    p, m, v = p0.clone(), torch.zeros(numel, device=DEV), torch.zeros(numel, device=DEV)
+    hyper = torch.tensor([1e-3 / (1 - 0.9), 1.0 / (1 - 0.999) ** 0.5, 1e-8, 0.0], device=DEV)
+    unet_ops.adam_step(p, torch.zeros(numel, device=DEV), m, v, hyper, 0.9, 0.999)
+    assert torch.equal(p, p0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0
+    hyper[3] = 1e-2
+    unet_ops.adam_step(p, torch.zeros(numel, device=DEV), m, v, hyper, 0.9, 0.999)
+    moved = (p0 - p)
+    big = p0.abs() > 1e-3
+    assert bool((moved[big].sign() == p0[big].sign()).all()) and float((moved[big].abs() - 1e-3).abs().max()) <= 2e-6
