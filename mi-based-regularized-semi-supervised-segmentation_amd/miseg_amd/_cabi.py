@@ -122,8 +122,16 @@ def call(name: str, *args, work=None, tag=None) -> None:
         raise MisegError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")
 
 
+_QUERY_CACHE: dict = {}
+
+
 def query(name: str, *args) -> int:
-    v = getattr(lib(), name)(*args)
-    if v < 0:
-        raise MisegError(f"{name}{args} -> {v}: unsupported configuration")
-    return int(v)
+    """A size / capability query of the library (pure functions of their arguments: cached -- a backward pass asks ~150 of them)."""
+    key = (name,) + args
+    v = _QUERY_CACHE.get(key)
+    if v is None:
+        v = getattr(lib(), name)(*args)
+        if v < 0:
+            raise MisegError(f"{name}{args} -> {v}: unsupported configuration")
+        v = _QUERY_CACHE[key] = int(v)
+    return v
