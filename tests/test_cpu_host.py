@@ -292,6 +292,32 @@ def test_deferred_readback_ticket_order_and_flush():
         checks.raise_if_nan(torch.tensor(float("nan")), "inline")
 
 
+def test_pending_precompute_gives_the_guard_flags_and_keeps_the_report_for_the_post():
+    """`_Pending.precompute` (called before the optimiser launch): evaluates values and check flags once, returns the flag part
+    (the device-side guard of the Adam launch) and leaves the vector for the iteration's post / fetch -- same values, same
+    exceptions, nothing evaluated twice and nothing left over for the next iteration."""
+    from miseg_amd import checks
+    from miseg_amd.lazy import LinearLoss
+    from semi_seg.epocher import _Pending
+    pend = _Pending()
+    a, b = torch.tensor(2.0), torch.tensor([1.0, 3.0])
+    pend.put("sup_loss", LinearLoss.of(a) * 0.5)
+    pend.put("mi", -LinearLoss.mean(b))
+    assert pend.precompute() is None or pend.precompute().numel() == 0            # no checks recorded: nothing to guard with
+    assert pend.fetch() == {"sup_loss": 1.0, "mi": -2.0} and pend.fetch() == {}
+    with checks.deferred(pend.checks):
+        checks.require_zero(torch.tensor(0, dtype=torch.int32), AssertionError, "simplex")
+        checks.raise_if_nan(torch.tensor([0.5, float("nan"), float("nan")]), "a patch loss is nan")
+    pend.put("sup_loss", a)
+    flags = pend.precompute()
+    assert flags.tolist() == [0.0, 2.0]                                           # integer counter cast, number of NaNs
+    assert not pend.checks and not pend._vals                                     # moved into the kept report
+    assert pend.precompute().tolist() == [0.0, 2.0]                               # idempotent until consumed
+    with pytest.raises(RuntimeError, match="a patch loss is nan"):
+        _Pending.wait(pend.post())
+    assert pend.precompute() is None
+
+
 def _build_trainer(name, save_dir, device="cpu", size=32):
     import yaml
     from contrastyou.arch import UNet
