@@ -284,10 +284,29 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         if graph is not None and self._reducer is None and labeled_image.is_cuda:
             inter, union = graph.run(labeled_image, labeled_target, unlabeled_image, flip_masks, seed)
         else:
-            flips2 = torch.tensor(flip_masks, dtype=torch.int32, device=labeled_image.device)   # one host->device copy
+            flips2 = self._upload_flips(flip_masks, labeled_image.device)
             self._optimizer.advance() if hasattr(self._optimizer, "advance") else None
             inter, union = self._device_step(labeled_image, labeled_target, unlabeled_image, flips2, seed)
         return inter, union, label_group
+
+    _flip_ring = None
+
+    def _upload_flips(self, flip_masks, device) -> Tensor:
+        """The iteration's flip masks on the device.  From PINNED memory with a non-blocking copy (four slots round-robin: the host
+        runs up to two iterations ahead of the copy engine): `torch.tensor(list, device=cuda)` copies from pageable memory, which
+        hipMemcpy does synchronously -- the host then waits for the queue to drain at the top of EVERY iteration, and the launches
+        of the next step's head are exposed (a replayed step graph, which stages its masks like this, was 0.3 ms ahead of eager)."""
+        if device.type != "cuda" or os.environ.get("MISEG_PINNED_FLIPS", "1") == "0":     # the switch: same-box A/B only
+            return torch.tensor(flip_masks, dtype=torch.int32, device=device)
+        ring = self._flip_ring
+        if ring is None or ring[0].shape[1] != len(flip_masks):
+            ring = self._flip_ring = [torch.zeros(4, len(flip_masks), dtype=torch.int32).pin_memory(), 0]
+        ring[1] = (ring[1] + 1) % 4
+        host = ring[0][ring[1]]
+        host.copy_(torch.as_tensor(flip_masks, dtype=torch.int32))
+        out = torch.empty(len(flip_masks), dtype=torch.int32, device=device)
+        out.copy_(host, non_blocking=True)
+        return out
 
     def _before_forward(self, ub: int) -> None:   # hooks for epochers that start work while the network is still running
         pass
