@@ -18,7 +18,16 @@ from ._cabi import BF16, F16, F32, call, query
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The current HIP stream's handle.  Asked ~90 times per training step: `torch.cuda.current_stream().cuda_stream` builds a Python
+    Stream object each time (9 us, 0.85 ms of host time per step -- the host is co-critical at this step time); the two raw
+    bindings cost well under a microsecond."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
