@@ -313,8 +313,13 @@ class _GradJoin:
     stream wait for that kernel, and returns no gradient of its own.  No offer (another tap, another order, an unsupported shape):
     the head returns its gradient as before.  The protocol is symmetric -- whoever runs first returns its tensor to autograd AND
     offers it, whoever runs second and can accumulate takes it and returns None: at the 32-channel tap the head runs first and
-    ``up_conv``'s pooled data gradient (``miseg_conv3x3_fwd_sumpool_acc``) is the one that adds.  ``MISEG_GRAD_JOIN=0`` disables."""
-    enabled = os.environ.get("MISEG_GRAD_JOIN", "1") != "0"
+    ``up_conv``'s pooled data gradient (``miseg_conv3x3_fwd_sumpool_acc``) is the one that adds.
+
+    OFF unless ``MISEG_GRAD_JOIN=1``: once the per-step host synchronisation was gone and same-box repeats agreed to 0.02 ms, three
+    alternations read 7.32 / 7.30 / 7.33 ms without, 7.34 / 7.34 / 7.36 with the join at the 16-channel tap only, 7.44 / 7.43 / 7.44 at the
+    32-channel tap only, 7.41 with both -- the cross-stream waits the hand-over adds cost more than the add kernels it removes."""
+    enabled = os.environ.get("MISEG_GRAD_JOIN", "0") == "1"
+    only = os.environ.get("MISEG_GRAD_JOIN_ONLY", "")      # "16" / "32": join at taps of that width only (the measurements below)
     _offers: dict = {}
 
     @classmethod
@@ -458,7 +463,8 @@ class _LocalHead(torch.autograd.Function):
         gprob = gprob.contiguous().float()
         gfeat = None
         joined = None
-        if ctx.needs_input_grad[0] and query("miseg_head_local_bwd_acc_supported", _DT[feat.dtype], c, s, k):
+        if ctx.needs_input_grad[0] and query("miseg_head_local_bwd_acc_supported", _DT[feat.dtype], c, s, k) and \
+                (not _GradJoin.only or _GradJoin.only == str(c)):
             joined = _GradJoin.take(feat)
         if joined is not None:
             # the other consumer of this feature already wrote its input gradient: add ours to it in the kernel epilogue

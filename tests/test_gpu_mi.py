@@ -9,6 +9,8 @@ loss that can itself be 1e-6.  We therefore require
     relative to the entropy scale, AND no worse than 4x the reference's own fp32 deviation + 1e-7;
   * gradients: 1e-4 of the gradient scale vs the fp64 oracle (fp32 reference itself is at that level).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -453,6 +455,8 @@ def test_head_backward_joins_an_offered_gradient(h, w):
     cot = T(synth.normal(f"join/{h}/cot", (s, 4, k, h, w))).to(DEV)
     base = T(synth.normal(f"join/{h}/g0", (bsz, c, h, w))).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
+    O._GradJoin.enabled = True      # opt-in feature (MISEG_GRAD_JOIN=1)
+
     def run(offer):
         f = feat.clone(memory_format=torch.preserve_format).requires_grad_(True)
         w_, b_ = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
@@ -475,6 +479,7 @@ def test_head_backward_joins_an_offered_gradient(h, w):
     bound = 2.0 ** -8 * (base.float().abs() + 2 * g_alone.float().abs()) + 1e-6        # rounding of the sum + the bf16 rounding of g_alone itself
     assert bool((err <= bound).all()), float((err / bound).max())
     assert torch.equal(gw_a, gw_j) and torch.equal(gb_a, gb_j)
+    O._GradJoin.enabled = os.environ.get("MISEG_GRAD_JOIN", "0") == "1"
 
 
 @pytest.mark.parametrize("c,h,w", [(32, 40, 48), (16, 6, 10), (16, 72, 36)])
