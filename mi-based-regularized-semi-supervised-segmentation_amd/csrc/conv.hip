@@ -1187,7 +1187,11 @@ extern "C" int miseg_conv3x3_bn_fwd(void* stream, int dt, const void* in0, int64
 static int wgrad_splits(int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
     const int64_t ntiles = N * cdiv(H, WG_TH) * cdiv(W, WG_TW);
     const int64_t per = cdiv(Cin, 32) * cdiv(Cout, 32);
-    static const int target = [] { const char* e = getenv("MISEG_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    // Blocks a weight-gradient launch is split into.  The launches run on their own stream beside the main stream's backward: with 512
+    // the wgrad kernels themselves are fastest (1.86 ms per step in total), with 256 they take 1.96 ms but the STEP is 0.14 ms
+    // shorter (7.13 vs 7.27 ms, same box, two alternations; 192: 7.18-7.35, 128: 7.31-7.47) -- one block per CU leaves the other
+    // half of every CU's wave slots and LDS to the critical-path kernels.
+    static const int target = [] { const char* e = getenv("MISEG_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
     int64_t s = std::max<int64_t>(1, target / per);
     return (int)std::min<int64_t>(s, ntiles);
 }
