@@ -388,7 +388,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-static inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 8192)); }
+static inline int ew_blocks(int64_t n) {
+    static const int64_t cap = [] { const char* e = getenv("MISEG_EW_BLOCKS"); return e ? atoll(e) : 8192LL; }();      // grid-stride elementwise kernels
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), cap));
+}
 static const int64_t kFinishFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
 static inline int red_blocks(int64_t npix, int CV) {
     (void)CV;
@@ -476,7 +479,7 @@ extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, con
         MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     }
     // elementwise pass: many more blocks than the reduce (no partials to bound), same thread -> channel-vector mapping
-    const int na = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv((gpool ? npix / 4 : npix) * CV, 256), 8192));
+    const int na = ew_blocks((gpool ? npix / 4 : npix) * CV);
 #define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw)
     if (dt == MISEG_F32) { if (gpool) APP(float, true); else APP(float, false); }
     else { if (gpool) APP(bf16, true); else APP(bf16, false); }

@@ -1035,7 +1035,10 @@ extern "C" int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void
 static bool conv_streams(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
     return dt == MISEG_BF16 && Cin <= CK && tile_w(W) == 32 && N * cdiv(H, TH) * cdiv(W, 32) >= 512 && !getenv("MISEG_NO_STREAM");
 }
-static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) { return std::min<int64_t>(N * cdiv(H, TH) * cdiv(W, 32), 512); }
+static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
+    static const int64_t cap = [] { const char* e = getenv("MISEG_STREAM_BLOCKS"); return e ? atoll(e) : 512LL; }();    // persistent blocks (2 per CU)
+    return std::min<int64_t>(N * cdiv(H, TH) * cdiv(W, 32), cap);
+}
 
 // tile height of the generic kernel (bf16): 8 rows from 64^2 upwards (smaller LDS tile -> two blocks per CU; measured
 // 128^2 64->32: 78 -> 64 us), 16 rows for the small deep layers (32^2: 8-row tiles cost 46 -> 55 us) and for exact fp32
