@@ -56,7 +56,9 @@ const char* miseg_last_error(void);
  * like the reference's crop (:158) followed by conv2d(padding=pad) (:123).  mask: fp32 [N,1,H,W]
  * or NULL (:115-117).
  * precision : 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32); 1 = bf16 MFMA with hi/lo operand split (3 products,
- *             fp32-class accuracy); 2 = plain bf16 operands.  1/2 fall back to 0 for shapes the bf16 kernels do not cover.
+ *             fp32-class accuracy); 2 = plain bf16 operands; 3 = f16 hi x hi + both cross terms on the block-scaled fp8 MFMA
+ *             (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3): the accuracy class of 1 at 2/3 of its matrix time; kernels without that
+ *             form run 1.  1/2/3 fall back to 0 for shapes the 16-bit kernels do not cover.
  * joint_fwd : raw[P][T][T][K][K] (T = 2*pad+1), raw[p][a][b][i][j] =
  *             sum_{n,h,w} Xpad[n,i,h+a,w+b] * Y[n,j,h,w]              (the conv2d at :120-123)
  * loss_fwd  : per window: global-min shift +1e-16 (:124), per-displacement normalise (:129),

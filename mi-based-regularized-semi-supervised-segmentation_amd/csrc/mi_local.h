@@ -64,57 +64,17 @@ static inline size_t joint_lds_bytes(const JointGeom& g) {
 }
 
 
-// The MT x NT tiles of D in row-major order, cut into four runs: wave `ROLE` of a quad owns one run (~MT*NT/4 accumulator
-// tiles = 84 registers at 9 x 9), so two waves fit a SIMD and one's LDS phases can hide under the other's MFMAs.
-template <int MT, int NT, int ROLE>
-struct QuadTiles {
-    static constexpr int PER = (MT * NT + 3) / 4;
-    static constexpr bool mine(int m, int n) { return (m * NT + n) / PER == ROLE; }
-    static constexpr bool row_used(int m) {
-        for (int n = 0; n < NT; ++n)
-            if (mine(m, n)) return true;
-        return false;
-    }
-    static constexpr bool col_used(int n) {
-        for (int m = 0; m < MT; ++m)
-            if (mine(m, n)) return true;
-        return false;
-    }
-    static constexpr int first_col() {
-        for (int n = 0; n < NT; ++n)
-            if (col_used(n)) return n;
-        return 0;
-    }
-    static constexpr int next_col(int n) {      // next used column after n, NT if none
-        for (int k = n + 1; k < NT; ++k)
-            if (col_used(k)) return k;
-        return NT;
-    }
-    static constexpr int nth_col(int j) {       // j-th used column, NT if there are fewer
-        int r = 0;
-        for (int k = 0; k < NT; ++k)
-            if (col_used(k)) {
-                if (r == j) return k;
-                ++r;
-            }
-        return NT;
-    }
-    static constexpr int col_rank(int n) {      // how many used columns precede n
-        int r = 0;
-        for (int k = 0; k < n; ++k) r += col_used(k) ? 1 : 0;
-        return r;
-    }
-};
-
-int launch_joint_fwd_bf16(hipStream_t st, const float* x, const float* y, const float* mask, const JointGeom& g, const int32_t* win,
-                          float* partials, int nterms);
+// bf16 / f16 matrix-core paths of the joint (mi_local_fwd_px.hip) and of its backward (mi_local_bwd_rows.hip, mi_local_bwd_f8.hip).
+// nterms: 1 = plain bf16 operands, 3 = bf16 hi/lo split (three products), 2 = f16 hi x hi + fp8 cross terms (backward, pad 3)
 bool joint_fwd_bf16_supported(const JointGeom& g);
 int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& g, const int32_t* win, float* partials, int nterms);
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad);
 size_t local_bwd_bf16_ws_bytes(int64_t K, int64_t pad, int64_t P);
-int launch_local_bwd_bf16(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad,
-                          const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy, int accumulate,
-                          void* ws, int nterms);
+bool local_bwd_f8_supported(int64_t K, int64_t pad);
+size_t local_bwd_f8_ws_bytes(int64_t K, int64_t pad, int64_t P);
+int launch_local_bwd_f8(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
+                        int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
+                        int accumulate, void* ws);
 
 int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                           int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,

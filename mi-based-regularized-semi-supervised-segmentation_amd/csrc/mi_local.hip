@@ -640,6 +640,9 @@ __global__ __launch_bounds__(kThreads, 1) void local_bwd2_kernel(const float* __
 
 using namespace miseg;
 
+// precision (include/miseg_hip.h) -> products per fp32-class product: 1 = bf16x3, 2 = plain bf16, 3 = f16 + fp8 cross terms
+static inline int nterms_of(int precision) { return precision == 1 ? 3 : precision == 3 ? 2 : 1; }
+
 extern "C" int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
     JointGeom g;
     if (N <= 0 || K <= 0 || P <= 0 || pad < 0 || !plan_joint(g, N, K, H, W, pad, P)) return -1;
@@ -661,7 +664,7 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
     hipStream_t st = as_stream(stream);
     const int cap = g.tilesM <= 4 ? 4 : 9;
     if (precision != 0 && mask == nullptr && joint_fwd_bf16_supported(g)) {   // 1: bf16 x3 split (fp32-class), 2: plain bf16
-        launch_joint_fwd_bf16(st, x, y, mask, g, win, (float*)ws, precision == 1 ? 3 : 1);
+        launch_joint_fwd_px(st, x, y, g, win, (float*)ws, nterms_of(precision));
     } else if (cap == 4) {
         hipFuncSetAttribute((const void*)joint_fwd_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL((joint_fwd_kernel<4, 4>), grid, block, ldsb, st, x, y, mask, g, win, (float*)ws);
@@ -691,8 +694,8 @@ extern "C" int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs,
         const int cap = g.tilesM <= 4 ? 4 : 9;
         JointGeom gh = g;                    // planned for P*S slots (sets G); the kernel sees P windows x S heads
         gh.P = (int)P; gh.S = (int)S; gh.hs = hs;
-        launch_joint_fwd_bf16(st, probs, probs + UB * K * H * W, nullptr, gh, win, (float*)ws, precision == 1 ? 3 : 1);
-        MISEG_LAUNCH_CHECK("joint_fwd_bf16_kernel");
+        launch_joint_fwd_px(st, probs, probs + UB * K * H * W, gh, win, (float*)ws, nterms_of(precision));
+        MISEG_LAUNCH_CHECK("joint_fwd_px_kernel");
         const int64_t total = P * S * TT * K * K;
         hipLaunchKernelGGL(joint_reduce_kernel, dim3(reduce_grid(total, g.G)), dim3(256), 0, st, (const float*)ws, g, cap, raw);
         MISEG_LAUNCH_CHECK("joint_reduce_kernel");
@@ -714,9 +717,9 @@ extern "C" int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64
     const int64_t hs = 2 * UB * K * H * W, half = UB * K * H * W, TT = (2 * pad + 1) * (2 * pad + 1);
     if (precision != 0 && local_bwd_bf16_supported(UB, K, H, W, pad)) {
         MISEG_REQUIRE(ws && ws_bytes >= (int64_t)local_bwd_bf16_ws_bytes(K, pad, P * S), "iic_local_bwd_heads: workspace too small");
-        launch_local_bwd_bf16(as_stream(stream), probs, probs + half, S, hs, UB, K, H, W, pad, win, P, grad_raw, scale, gprob, gprob + half,
-                              accumulate, ws, precision == 1 ? 3 : 1);
-        MISEG_LAUNCH_CHECK("local_bwd_bf16_kernel");
+        launch_local_bwd_rows(as_stream(stream), probs, probs + half, S, hs, UB, K, H, W, pad, win, P, grad_raw, scale, gprob, gprob + half,
+                              accumulate, ws, nterms_of(precision));
+        MISEG_LAUNCH_CHECK("local_bwd_rows_kernel");
         return MISEG_OK;
     }
     for (int64_t s = 0; s < S; ++s) {
@@ -772,8 +775,8 @@ extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y,
     hipStream_t st = as_stream(stream);
     if (precision != 0 && mask == nullptr && local_bwd_bf16_supported(N, K, H, W, pad)) {   // bf16 MFMA, hi/lo split (1) or plain (2)
         MISEG_REQUIRE(ws && ws_bytes >= (int64_t)local_bwd_bf16_ws_bytes(K, pad, P), "iic_local_bwd: workspace too small for the bf16 path");
-        launch_local_bwd_bf16(st, x, y, 1, 0, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, precision == 1 ? 3 : 1);
-        MISEG_LAUNCH_CHECK("local_bwd_bf16_kernel");
+        launch_local_bwd_rows(st, x, y, 1, 0, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, nterms_of(precision));
+        MISEG_LAUNCH_CHECK("local_bwd_rows_kernel");
         return MISEG_OK;
     }
     {   // fast path: transposed GEMM + LDS col2im (needs T*K <= 144 rows and the G matrix + tiles in LDS)

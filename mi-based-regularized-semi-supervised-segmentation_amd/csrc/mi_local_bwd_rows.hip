@@ -169,7 +169,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
             const unsigned vb = (rok && lane < C::WS - 64 && cb >= w0w && cb < w1w) ? (unsigned)cb * 4u : OOB;
             // per-lane byte offset of the column in voffset (out of range = dropped), the wave-uniform row / channel part in soffset:
             // no vector add per load
-            const unsigned rowoff = ((unsigned)(n * K) * (unsigned)plane + (unsigned)(rok ? hsr : 0) * (unsigned)g.W) * 4u;
+            // wave-uniform, and SAID so: left to itself the compiler folds `rok` into the lanes' column tests, keeps this offset in a VGPR
+            // and wraps every load below in a waterfall loop (readfirstlane / compare / saveexec / branch per load)
+            const unsigned rowoff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(n * K) * (unsigned)plane + (unsigned)(rok ? hsr : 0) * (unsigned)g.W) * 4u));
 #pragma unroll
             for (int c = 0; c < K; ++c) {
                 const unsigned so = rowoff + (unsigned)c * (unsigned)plane * 4u;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
             // array needs a compile-time index; nothing is written back) and store it if it belongs to this unit
             const int h = hsr - PAD;
             const bool keep = h >= r0;                     // h < r1 by construction of hs_last
-            const unsigned rowo = ((unsigned)(n * K) * (unsigned)plane + (unsigned)(keep ? h : 0) * (unsigned)g.W + (unsigned)col0) * 4u;   // wave-uniform
+            const unsigned rowo = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(n * K) * (unsigned)plane + (unsigned)(keep ? h : 0) * (unsigned)g.W + (unsigned)col0) * 4u));   // wave-uniform
             f32x4 done[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) done[nt] = zero4;
@@ -381,9 +383,14 @@ static size_t rows_lds(int nterms) {
     return (size_t)C::KS * np * C::MP * 32 * 2 + (size_t)WAVES * ((WAVES > 8 || (WAVES == 8 && NTW == 4)) ? 1 : 2) * np * C::WSP * C::CS * 2;
 }
 
-size_t local_bwd_rows_ws_bytes(int64_t K, int64_t pad, int64_t P) {
+bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad) {
+    return K == 20 && (pad == 3 || pad == 1) && (size_t)N * K * H * W * 4 < 0x40000000ull;       // 32-bit buffer offsets with an out-of-range marker
+}
+
+// packed gradient matrices of all (sub-head, window, direction) triples: the larger of the two kernels' images
+size_t local_bwd_bf16_ws_bytes(int64_t K, int64_t pad, int64_t P) {
     const int T = 2 * (int)pad + 1, MP = (T + (T * 4 + 15) / 16) * 16, KS = (T * (int)K + 31) / 32;
-    return (size_t)P * 2 * KS * 2 * MP * 32 * 2;
+    return std::max((size_t)P * 2 * KS * 2 * MP * 32 * 2, local_bwd_f8_ws_bytes(K, pad, P));
 }
 
 template <int K, int PAD, int NTW, int WAVES>
@@ -407,6 +414,10 @@ static int launch_rows(hipStream_t st, const float* x, const float* y, RowsGeom 
 int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                           int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
                           int accumulate, void* ws, int nterms) {
+    if (nterms == 2) {        // f16 hi x hi + fp8 cross terms where that kernel exists (pad 3), the bf16 split elsewhere
+        if (local_bwd_f8_supported(K, pad)) return launch_local_bwd_f8(st, x, y, S, hs, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws);
+        nterms = 3;
+    }
     RowsGeom g{(int)N, (int)H, (int)W, (int)P, (int)S, accumulate, 256, (long long)hs};
     // Shape of a block = waves x strip width.  Measured on the cfg2 launch (S=5, N=16, 256^2, pad 3; bench, same box): 12x32 1.14 ms,
     // 8x32 1.17, 8x64 1.19, 4x64 1.31-1.38 (one wave per SIMD: nothing covers a wave's row-end fetch / split / store phase); the

@@ -360,7 +360,13 @@ static size_t px_lds(int nterms) {
     return rows > dred ? rows : dred;
 }
 
+bool joint_fwd_bf16_supported(const JointGeom& g) {
+    if (g.sb != 1 || g.K != 20 || (g.pad != 3 && g.pad != 1)) return false;
+    return (size_t)g.N * g.K * g.H * g.W * 4 < 0x40000000ull;                  // 32-bit buffer offsets with an out-of-range marker
+}
+
 int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& jg, const int32_t* win, float* partials, int nterms) {
+    if (nterms == 2) nterms = 3;     // the f16 + fp8 split exists for the backward only (mi_local_bwd_f8.hip)
     PxGeom g{jg.N, jg.H, jg.W, jg.P, jg.S, jg.G, jg.hs};
     dim3 grid(g.G, g.P * g.S), block(kPT);
 #define PXL(PADV, NT_)                                                                                                           \

@@ -82,13 +82,15 @@ def flips_to_tensor(decisions: Sequence[Sequence[bool]], device) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------ local MI
-MI_PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+MI_PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16f8": 3}
 _mi_precision = MI_PRECISIONS.get(__import__("os").environ.get("MISEG_MI_PRECISION", "fp32"), 0)
 
 
 def set_mi_precision(mode: str) -> None:
     """Arithmetic of the local-MI contraction: 'fp32' (exact fp32 MFMA, default), 'bf16x3' (bf16 MFMA on hi/lo-split
-    operands: fp32-class accuracy at 3/16 of the MFMA time) or 'bf16' (plain bf16 operands)."""
+    operands: fp32-class accuracy at 3/16 of the MFMA time), 'f16f8' (f16 hi x hi + both cross terms K-concatenated on the
+    block-scaled fp8 pipe: the same accuracy class at 2/3 of bf16x3's matrix time; kernels that have no such form take bf16x3)
+    or 'bf16' (plain bf16 operands)."""
     global _mi_precision
     _mi_precision = MI_PRECISIONS[mode]
 

@@ -103,12 +103,13 @@ def _record(name, got, truth):
         json.dump(_REL_ERRORS, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8"])
 def test_peaked_inputs_hold_1e5_relative(golden, precision):
     """north_star: 'softmax/MI loss within 1e-5 rel fp32'.  On correlated, peaked inputs (MI 0.18 .. 1.45; golden cases gpeak_* /
     lpeak_* / ppeak_* produced by the reference) the bound is applied LITERALLY: |hip - reference| <= 1e-5 |reference| against the
     reference's own fp32 result, and against an fp64 evaluation of the same fp32 inputs; gradients 1e-4 of their scale.
-    bf16x3 = the bench's local-MI arithmetic (hi/lo-split bf16 MFMA), held to the same bound."""
+    bf16x3 / f16f8 = the matrix-core arithmetics of the local-MI kernels (hi/lo-split bf16 MFMA; f16 hi x hi + fp8 cross terms in the
+    backward, the bench's arithmetic), held to the same bound."""
     g = golden("iic")
     ops().set_mi_precision(precision)
     try:
@@ -306,9 +307,10 @@ def test_joint_bf16_split_matches_fp32_kernel(n, k, h, w, p):
             assert e_split <= 4 * e_ref + max(1e-6, 3e-5 / npix ** 0.5) * scale, (e_split, e_ref)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16f8"])
 @pytest.mark.parametrize("n,h,w,p", [(4, 32, 32, 3), (4, 32, 32, 1), (3, 70, 90, 3), (2, 37, 45, 3), (1, 7, 5, 1), (5, 9, 131, 3)])
-def test_local_mi_bf16_split_fwd_bwd_matches_fp64(n, h, w, p):
-    """Whole local-MI op (joint -> loss -> backward) in 'bf16x3' precision vs the fp64 oracle: same bounds as the fp32 path."""
+def test_local_mi_bf16_split_fwd_bwd_matches_fp64(n, h, w, p, precision):
+    """Whole local-MI op (joint -> loss -> backward) in 'bf16x3' / 'f16f8' precision vs the fp64 oracle: same bounds as the fp32 path."""
     k = 20
     gen = torch.Generator(device="cpu").manual_seed(n * 100 + h + p)
     x0 = torch.randn(n, k, h, w, generator=gen).softmax(1)
@@ -316,7 +318,7 @@ def test_local_mi_bf16_split_fwd_bwd_matches_fp64(n, h, w, p):
     x64, y64 = x0.double().requires_grad_(True), y0.double().requires_grad_(True)
     truth = OI.iid_seg_loss(x64, y64, p)
     gx64, gy64 = torch.autograd.grad(truth, [x64, y64])
-    ops().set_mi_precision("bf16x3")
+    ops().set_mi_precision(precision)
     try:
         x, y = x0.to(DEV).requires_grad_(True), y0.to(DEV).requires_grad_(True)
         loss = ops().local_mi_losses(x, y, p, [(0, h, 0, w)])[0]
@@ -397,8 +399,9 @@ def test_local_head_counts_simplex_violations_for_free():
     assert int(checks.simplex_violations(bad2, 2)) == 1
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16f8"])
 @pytest.mark.parametrize("pad,h,w,patch,s,ub", [(3, 64, 64, 32, 3, 2), (1, 48, 80, 32, 3, 2), (3, 512, 512, 128, 2, 1)])
-def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch, s, ub):
+def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch, s, ub, precision):
     """K=20 (the shipped cluster count) puts `forward_heads` on the batched bf16 kernels: S sub-heads x P overlapping
     patch windows in one launch forward, one launch per colour group backward (accumulating).  Compared with the exact-fp32
     kernels run one sub-head at a time (themselves pinned to the golden vectors above): loss to 5e-7 absolute; gradients
@@ -410,7 +413,7 @@ def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch, s, ub):
     base = T(synth.probs(f"bf16heads_p{pad}_h{h}_w{w}", (s * 2 * ub, k, h, w))).view(s, 2 * ub, k, h, w).to(DEV)
     wts = torch.arange(1, s + 1, device=DEV, dtype=torch.float32)
     try:
-        ops().set_mi_precision("bf16x3")
+        ops().set_mi_precision(precision)
         a = base.clone().requires_grad_(True)
         fused = crit.forward_heads(a, ub)
         (fused * wts).sum().backward()
@@ -428,7 +431,7 @@ def test_bf16x3_batched_heads_with_overlapping_patches(pad, h, w, patch, s, ub):
         wins = _windows(h, w, (patch, patch), (patch // 2, patch // 2))
         assert len(wins) == 49 and wins[-1] == (384, 512, 384, 512)
         try:
-            ops().set_mi_precision("bf16x3")
+            ops().set_mi_precision(precision)
             per_window = ops().local_mi_heads(base.clone().requires_grad_(True), ub, pad, wins).detach().cpu()   # [S, 49]
         finally:
             ops().set_mi_precision("fp32")
@@ -710,7 +713,7 @@ def test_joint_checksum_at_full_size(s, ub, h, w, pad, patch, precision):
     assert float((swapped - mirror).abs().max()) <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8"])
 @pytest.mark.parametrize("s,ub,h,w,pad,quad", [(5, 16, 256, 256, 3, False), (5, 16, 256, 256, 1, False), (3, 4, 256, 256, 3, True)])
 def test_backward_neighbour_count_at_full_size(s, ub, h, w, pad, quad, precision):
     """The local-MI backward at BASELINE cfg2's full size through the batched launch, checked by a closed form: with dLoss/draw = 1
@@ -731,7 +734,7 @@ def test_backward_neighbour_count_at_full_size(s, ub, h, w, pad, quad, precision
     nb = _cabi.query("miseg_iic_local_bwd_ws_bytes", k, pad, P * s)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     _cabi.call("miseg_iic_local_bwd_heads", torch.cuda.current_stream().cuda_stream, probs.data_ptr(), s, ub, k, h, w, pad, win.data_ptr(), P,
-               graw.data_ptr(), scale.data_ptr(), gprob.data_ptr(), 0, {"fp32": 0, "bf16x3": 1}[precision], ws.data_ptr(), ws.numel())
+               graw.data_ptr(), scale.data_ptr(), gprob.data_ptr(), 0, {"fp32": 0, "bf16x3": 1, "f16f8": 3}[precision], ws.data_ptr(), ws.numel())
     want = torch.zeros(h, w, dtype=torch.float64)
     for h0, h1, w0, w1 in wins:
         r, c = torch.arange(h0, h1), torch.arange(w0, w1)
