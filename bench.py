@@ -31,9 +31,10 @@ import torch  # noqa: E402
 
 FEATURES = ["Conv5", "Up_conv3", "Up_conv2"]
 PEAK = {"mfma_bf16": 2500.0, "mfma_f32": 157.3, "hbm": 8000.0}  # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
-# What the board SUSTAINS with every matrix pipe full, register-resident random bf16 operands and no memory traffic
-# (profiles/microbench/mfma_sustained.hip, measured in round 2: 1.20-1.26 PFLOP/s at 2-8 waves per SIMD; power-managed).
-SUSTAINED_MFMA_BF16 = 1250.0
+# What a register-resident loop of each local-MI instruction mix sustains on this board, [1 ms bursts every 7 ms, continuous] in
+# T(FL)OP/s of the instructions issued (profiles/microbench/r03_mfma_dtypes.txt: random operand bits, 2 waves per SIMD, no memory
+# traffic).  Round 2 quoted 1 250 here: that loop shuffled accumulators between the register files every iteration.
+MICROBENCH_SUSTAINED = {"bf16": [1824, 1999], "bf16x3": [1822, 2006], "f16f8": [2856, 3118]}
 
 
 def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
@@ -371,7 +372,9 @@ def main():
     table = []
     if survey is not None and survey.records:
         torch.cuda.synchronize()
-        table = sorted(survey.summary().items(), key=lambda kv: -kv[1]["total_ms"])
+        # ranked by calls x SHORTEST duration: an event pair around a kernel of a side stream also counts the time the kernel waited for
+        # compute units held by another stream's kernel (a 50 us head forward read 2 ms once) -- the shortest call did not wait
+        table = sorted(survey.summary().items(), key=lambda kv: -kv[1]["min_ms"] * kv[1]["calls"])
         if not use_graph:
             timer = _cabi.KernelTimer(only={table[0][0]})
             _cabi.TIMER = timer

@@ -100,7 +100,7 @@ class KernelTimer:
         out = {}
         for name, recs in self.records.items():
             ms = [s.elapsed_time(e) for s, e, _, _ in recs]
-            out[name] = {"calls": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+            out[name] = {"calls": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms), "min_ms": min(ms),
                          "flops_per_call": sum(r[2] for r in recs) / len(recs), "bytes_per_call": sum(r[3] for r in recs) / len(recs)}
         return out
 

@@ -383,7 +383,7 @@ def gen_step():
     from contrastyou.arch import UNet
     from deepclustering2.loss import KL_div
     from semi_seg._utils import ProjectorWrapper, IICLossWrapper
-    from semi_seg.epocher import UDAIICEpocher, TrainEpocher
+    from semi_seg.epocher import UDAIICEpocher, TrainEpocher, UDATrainEpocher, IICTrainEpocher
     import semi_seg.epocher as ref_epocher
     H, LB, UB, NB = (STEP_SHAPE[k] for k in ("H", "LB", "UB", "NB"))
     out = {}
@@ -401,7 +401,8 @@ def gen_step():
                                   for n, p in zip(self._names, ps)})
             return super().step(closure)
 
-    for mode in ("udaiic", "partial"):
+    # udaiic / partial: BASELINE configs; uda / iic: the SURVEY 8(f-4) trainers (semi_seg/epocher.py:200-284) on the same kind of state
+    for mode in ("udaiic", "partial", "uda", "iic"):
         cfg = yaml.safe_load(open(os.path.join(REF, "config", "semi.yaml")))
         fn = cfg["Trainer"]["feature_names"]
         fi = [float(v) for v in cfg["Trainer"]["feature_importance"]]
@@ -427,7 +428,7 @@ def gen_step():
         unl_loader = loader(unl, [torch.zeros(UB, 1, H, H, dtype=torch.long)] * NB, UB)
         # lr large enough that the update is visible in fp32 (the yaml's 1e-7 barely moves weights)
         named = chain(model.named_parameters(), ((f"proj/{n}", p) for n, p in pw.named_parameters())) \
-            if mode == "udaiic" else model.named_parameters()
+            if mode in ("udaiic", "iic") else model.named_parameters()
         opt = RecordingAdam(named, lr=STEP_SHAPE["lr"], weight_decay=STEP_SHAPE["wd"])
         seeds = []
         real_randint = random.randint
@@ -445,6 +446,12 @@ def gen_step():
                                    torch.nn.MSELoss(), lw, num_batches=NB, cur_epoch=0, device="cpu",
                                    feature_position=fn, feature_importance=fi,
                                    cons_weight=STEP_SHAPE["cons_weight"], iic_weight=STEP_SHAPE["iic_weight"])
+            elif mode == "uda":        # trainer.py:132-147: reg_weight = UDARegCriterion.weight
+                ep = UDATrainEpocher(model, opt, lab_loader, unl_loader, KL_div(verbose=False), torch.nn.MSELoss(),
+                                     STEP_SHAPE["cons_weight"], NB, 0, "cpu", feature_position=fn, feature_importance=fi)
+            elif mode == "iic":        # trainer.py:150-184: reg_weight = IICRegParameters.weight
+                ep = IICTrainEpocher(model, pw, opt, lab_loader, unl_loader, KL_div(verbose=False), lw,
+                                     STEP_SHAPE["iic_weight"], NB, 0, "cpu", feature_position=fn, feature_importance=fi)
             else:
                 ep = TrainEpocher(model, opt, lab_loader, unl_loader, KL_div(verbose=False), 0, NB, 0, "cpu",
                                   feature_position=fn, feature_importance=fi)
@@ -463,7 +470,7 @@ def gen_step():
             put_fp(out, f"{mode}/grad_step1/{n}", gr)
         for k, v in model.state_dict().items():
             put_fp(out, f"{mode}/model_after/{k}", v)
-        if mode == "udaiic":
+        if mode in ("udaiic", "iic"):
             for k, v in pw.state_dict().items():
                 put_fp(out, f"{mode}/proj_after/{k}", v)
         out[f"{mode}/feature_importance"] = np.asarray(fi)

@@ -137,7 +137,7 @@ def test_bench_line_contract():
     assert d["unit"] == "images/s" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]            # value = images of the timed steps / time
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms", "ceiling_frac", "sustained_peak"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms", "ceiling_frac", "microbench_sustained_TFLOPs"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["kernel"].startswith("iic_local_bwd") and r["peak"] == 2500.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 0.5 and r["avg_ms"] < d["ms_per_step"]

@@ -37,7 +37,7 @@ def build(mode, dtype="float32"):
     pw._decoder_projectors["Up_conv2"].load_state_dict(OH.init_local_cluster_head(16, 20, 5, "linear", seed=12))
     lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=1024)
     model, pw = model.to(DEV), pw.to(DEV)
-    params = chain(model.parameters(), pw.parameters()) if mode == "udaiic" else model.parameters()
+    params = chain(model.parameters(), pw.parameters()) if mode in ("udaiic", "iic") else model.parameters()     # semi_seg/trainer.py:150-184
     opt = Adam(params, lr=STEP["lr"], weight_decay=STEP["wd"])
 
     def loader(tag, B, with_tgt):
@@ -50,19 +50,31 @@ def build(mode, dtype="float32"):
     return model, pw, lw, opt, loader("lab", LB, True), loader("unl", UB, False), KL_div(verbose=False)
 
 
-@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+def make_epocher(mode, model, pw, lw, opt, lab, unl, kl, fi, num_batches):
+    """The epocher of `Trainer.name = mode` (semi_seg/trainer.py:132-195), constructed as the trainers do."""
+    from semi_seg.epocher import IICTrainEpocher, TrainEpocher, UDAIICEpocher, UDATrainEpocher
+    if mode == "udaiic":
+        return UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=num_batches, cur_epoch=0, device=DEV,
+                             feature_position=FEATURES, feature_importance=fi, cons_weight=STEP["cons_weight"], iic_weight=STEP["iic_weight"])
+    if mode == "uda":
+        return UDATrainEpocher(model, opt, lab, unl, kl, torch.nn.MSELoss(), STEP["cons_weight"], num_batches, 0, DEV,
+                               feature_position=FEATURES, feature_importance=fi)
+    if mode == "iic":
+        return IICTrainEpocher(model, pw, opt, lab, unl, kl, lw, STEP["iic_weight"], num_batches, 0, DEV, feature_position=FEATURES,
+                               feature_importance=fi)
+    return TrainEpocher(model, opt, lab, unl, kl, 0, num_batches, 0, DEV, feature_position=FEATURES, feature_importance=fi)
+
+
+MODES = ["udaiic", "partial", "uda", "iic"]      # BASELINE configs[1] / configs[0]; SURVEY 8(f-4): semi_seg/epocher.py:200-284
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_epocher_matches_reference_run(golden, mode):
-    from semi_seg.epocher import TrainEpocher, UDAIICEpocher
     g = golden("step")
     model, pw, lw, opt, lab, unl, kl = build(mode)
     fi = [float(v) for v in g[f"{mode}/feature_importance"]]
     random.seed(1234)
-    if mode == "udaiic":
-        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=STEP["NB"], cur_epoch=0, device=DEV,
-                           feature_position=FEATURES, feature_importance=fi, cons_weight=STEP["cons_weight"], iic_weight=STEP["iic_weight"])
-    else:
-        ep = TrainEpocher(model, opt, lab, unl, kl, 0, STEP["NB"], 0, DEV, feature_position=FEATURES, feature_importance=fi)
-    res = ep.run()
+    res = make_epocher(mode, model, pw, lw, opt, lab, unl, kl, fi, STEP["NB"]).run()
     got = {f"{k}/{kk}": float(vv) for k, v in res.items() for kk, vv in dict(v).items()}
     ref = dict(zip([str(k) for k in g[f"{mode}/meter_keys"]], g[f"{mode}/meter_values"]))
     assert set(got) == set(ref), set(got) ^ set(ref)                      # identical meter names
@@ -75,10 +87,12 @@ def test_epocher_matches_reference_run(golden, mode):
     for k in ("sup_dice/DSC1", "sup_dice/DSC2", "sup_dice/DSC3", "sup_dice/DSC_mean"):
         np.testing.assert_allclose(got[k], ref[k], rtol=2e-2, atol=5e-3)   # rare classes: a few pixels move a 1e-2 Dice
     np.testing.assert_allclose(got["reg_loss/mean"], ref["reg_loss/mean"], rtol=0.2, atol=1e-7)
-    if mode == "udaiic":
+    if mode in ("udaiic", "uda"):
         np.testing.assert_allclose(got["uda/mean"], ref["uda/mean"], rtol=0.2)
+    if mode in ("udaiic", "iic"):
         for k in ("mi/mean", "individual_mis/Conv5", "individual_mis/Up_conv3", "individual_mis/Up_conv2"):
             np.testing.assert_allclose(got[k], ref[k], rtol=0.2, atol=5e-6)
+    if mode == "udaiic":
         assert got["iic_weight/mean"] == ref["iic_weight/mean"] and got["uda_weight/mean"] == ref["uda_weight/mean"]
     # Weights after two Adam steps.  Adam moves every weight by ~lr per step whatever the gradient size, so comparing the weights
     # themselves says nothing about the gradients (a wrong-sign gradient would still land within 2*lr): the gradients are compared
@@ -115,27 +129,21 @@ def test_udaiic_step_bf16_runs_and_tracks_fp32(golden):
     assert abs(res["mi"]["mean"] - ref["mi/mean"]) < 0.5 * abs(ref["mi/mean"]) + 1e-4
 
 
-@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+@pytest.mark.parametrize("mode", MODES)
 def test_first_iteration_is_tight(golden, mode):
     """Iteration 1 (identical weights on both sides): every meter of the HIP epocher vs the oracle step, which is
     itself pinned to the reference run by tests/test_oracle_golden.py::test_full_step."""
     from oracle import step as OS
     from oracle import losses as OL
-    from semi_seg.epocher import TrainEpocher, UDAIICEpocher
     g = golden("step")
     model, pw, lw, opt, lab, unl, kl = build(mode)
     fi = [float(v) for v in g[f"{mode}/feature_importance"]]
     random.seed(1234)
-    if mode == "udaiic":
-        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0, device=DEV,
-                           feature_position=FEATURES, feature_importance=fi, cons_weight=STEP["cons_weight"], iic_weight=STEP["iic_weight"])
-    else:
-        ep = TrainEpocher(model, opt, lab, unl, kl, 0, 1, 0, DEV, feature_position=FEATURES, feature_importance=fi)
-    res = ep.run()
+    res = make_epocher(mode, model, pw, lw, opt, lab, unl, kl, fi, 1).run()
     H, LB, UB = STEP["H"], STEP["LB"], STEP["UB"]
     heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=10), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=11),
              "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=12)}
-    state = OS.StepState(OU.init_state(1, 4, seed=9), heads if mode == "udaiic" else {}, lr=STEP["lr"], weight_decay=STEP["wd"])
+    state = OS.StepState(OU.init_state(1, 4, seed=9), heads if mode in ("udaiic", "iic") else {}, lr=STEP["lr"], weight_decay=STEP["wd"])
     limg = T(synth.uniform(f"step/{mode}/lab0", (LB, 1, H, H)))
     ltgt = T(synth.integers(f"step/{mode}/tgt0", (LB, 1, H, H), 4))
     uimg = T(synth.uniform(f"step/{mode}/unl0", (UB, 1, H, H)))
@@ -147,8 +155,9 @@ def test_first_iteration_is_tight(golden, mode):
     dice.add(sc["pred"], ltgt.squeeze(1), group_name=[f"patient{j:03d}_00" for j in range(LB)])
     for k, v in dice.summary().items():
         np.testing.assert_allclose(res["sup_dice"][k], v, rtol=2e-3)   # integer counts; one argmax tie may move a pixel
-    if mode == "udaiic":
+    if mode in ("udaiic", "uda"):
         np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4)
+    if mode in ("udaiic", "iic"):
         np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
         for f in FEATURES:
             np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
@@ -158,7 +167,6 @@ def _first_iteration_gradients(mode, dtype, monkeypatch, wgrad_side=True, iic_si
     """Run iteration 1 of the epocher and return {reference parameter name: gradient} as the optimiser kernel sees them: the flat
     gradient buffer is cloned between FlatBuffers.collect() and miseg_adam_step (the only place all slots are final)."""
     from miseg_amd import unet_ops
-    from semi_seg.epocher import TrainEpocher, UDAIICEpocher
     monkeypatch.setattr(unet_ops, "_WGRAD_SIDE", wgrad_side)
     monkeypatch.setenv("MISEG_IIC_STREAM", "1" if iic_side else "0")
     model, pw, lw, opt, lab, unl, kl = build(mode, dtype)
@@ -171,16 +179,10 @@ def _first_iteration_gradients(mode, dtype, monkeypatch, wgrad_side=True, iic_si
 
     monkeypatch.setattr(unet_ops, "adam_step", spy)
     random.seed(1234)
-    if mode == "udaiic":
-        ep = UDAIICEpocher(model, pw, opt, lab, unl, kl, torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0, device=DEV,
-                           feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=STEP["cons_weight"],
-                           iic_weight=STEP["iic_weight"])
-    else:
-        ep = TrainEpocher(model, opt, lab, unl, kl, 0, 1, 0, DEV, feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25])
-    ep.run()
+    make_epocher(mode, model, pw, lw, opt, lab, unl, kl, [0.5, 0.25, 0.25], 1).run()
     assert len(grabbed) == 1
     flat, fb = grabbed[0].cpu() / float(opt.grad_scale), opt.flat      # fp16 mode: the kernel divides the static loss scale out
-    named = list(model.named_parameters()) + ([("proj/" + n, p) for n, p in pw.named_parameters()] if mode == "udaiic" else [])
+    named = list(model.named_parameters()) + ([("proj/" + n, p) for n, p in pw.named_parameters()] if mode in ("udaiic", "iic") else [])
     out = {}
     for name, p in named:
         o = fb.offset_of(p)
@@ -212,7 +214,7 @@ def _dump(tag, rows):
 
 
 @pytest.mark.parametrize("wgrad_side,iic_side", [(True, True), (False, False)])
-@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+@pytest.mark.parametrize("mode", MODES)
 def test_step_gradients_match_reference(golden, monkeypatch, mode, wgrad_side, iic_side):
     """Every parameter gradient of iteration 1 -- through the flat-gradient slots, the wgrad side stream, the IIC side stream, the
     symbolic loss seeding and the partial zero-fill of the tap gradient -- against the gradients the REFERENCE's own epocher handed
@@ -230,8 +232,16 @@ def test_step_gradients_match_reference(golden, monkeypatch, mode, wgrad_side, i
     bad = {k: v for k, v in worst.items() if v > 3e-2 and rows[k][2] > 1e-7}     # <= 1e-7: the global-MI head's gradients are fp32 noise
     assert not bad, bad
     tail = sorted(v for k, v in worst.items() if k.startswith(("Up_conv2", "DeConv")))
-    assert tail[len(tail) // 2] < 1e-4 and tail[0] < 1e-5 and tail[-1] < 2e-3, tail
-    if mode == "udaiic":
+    # The last block's errors are decided by WHICH activations of `Up_conv2.conv` sit within rounding distance of zero in a given batch
+    # (a flipped ReLU mask moves that layer's BatchNorm bias gradient by ~1e-3 relative): measured on the four fixture batches (round 3,
+    # gpurun_out/step_grad_errors_*) -- udaiic / partial: median 7e-6 / 8e-6, worst 3e-4 / 4e-4; uda: median 1.4e-4, worst 4.9e-3;
+    # iic: median 2.8e-3, worst 4.6e-3 (their batches have masks that differ in the block's first convolutions; the CPU oracle shows
+    # the same profile against the reference, tests/test_oracle_golden.py::test_full_step bounds it at 5e-3 of each tensor's scale).
+    # The logits layer is flip-free in all four and must be tight everywhere.
+    med, top = {"uda": (5e-4, 1.5e-2), "iic": (1e-2, 1.5e-2)}.get(mode, (1e-4, 2e-3))
+    assert tail[len(tail) // 2] < med and tail[0] < 1e-5 and tail[-1] < top, tail
+    assert max(v for k, v in worst.items() if k.startswith("DeConv")) < 2e-5, worst
+    if mode in ("udaiic", "iic"):
         dec_heads = sorted(v for k, v in worst.items() if "_decoder_projectors" in k)
         assert dec_heads[-1] < 2e-4, dec_heads
 
@@ -528,3 +538,116 @@ def test_first_iteration_non_default_configuration_matches_the_oracle(monkeypatc
     tight = {k: v for k, v in worst.items() if not k.startswith("Conv5/")}
     assert max(tight.values()) < 1e-3, {k: v for k, v in tight.items() if v >= 1e-3}
     assert max(loose.values()) < 2e-2, loose
+
+
+_CFG2_ORACLE = {}
+
+
+def _cfg2_oracle():
+    """ONE oracle step at BASELINE configs[1]'s shape (LB = UB = 16, 256 x 256, default taps / heads / paddings): ~35 s of CPU, shared
+    by the parametrisations below."""
+    if not _CFG2_ORACLE:
+        from oracle import step as OS
+        H, LB, UB = 256, 16, 16
+        heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=41), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=42),
+                 "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=43)}
+        limg, ltgt = T(synth.uniform("cfg2step/lab", (LB, 1, H, H))), T(synth.integers("cfg2step/tgt", (LB, 1, H, H), 4))
+        uimg = T(synth.uniform("cfg2step/unl", (UB, 1, H, H)))
+        random.seed(2468)
+        seed = random.randint(0, int(1e7))               # the flip seed the epocher draws for iteration 1 (ref epocher.py:146)
+        state = OS.StepState(OU.init_state(1, 4, seed=40), heads, lr=1e-3, weight_decay=1e-5)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
+        try:
+            sc, grads = OS.train_step(state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0,
+                                      iic_weight=0.1, do_update=False)
+        finally:
+            torch.set_num_threads(threads)
+        _CFG2_ORACLE.update(heads=heads, limg=limg, ltgt=ltgt, uimg=uimg, sc=sc, grads=grads)
+    return _CFG2_ORACLE
+
+
+@pytest.mark.parametrize("dtype,mi_precision", [("float32", "fp32"), ("bfloat16", "f16f8"), ("bfloat16", "bf16x3")])
+def test_whole_step_at_the_bench_shape_matches_the_oracle(monkeypatch, dtype, mi_precision):
+    """BASELINE configs[1] at its OWN size -- LB = UB = 16, 256 x 256, taps Conv5 / Up_conv3 / Up_conv2, 20 clusters x 5 sub-heads,
+    paddings [1, 3], whole-map patches -- one `udaiic` iteration (ref semi_seg/epocher.py:137-188, 308-323) of the HIP epocher against
+    the CPU oracle on the same weights and batch: sup / uda / mi / per-tap mi / reg_loss and the gradients of the logits layer and of
+    every head parameter.  fp32 mode at the tolerances of test_first_iteration_is_tight; bf16 mode (the bench's arithmetic, with
+    either matrix-core form of the local-MI contraction) at the tolerances of test_udaiic_step_bf16_runs_and_tracks_fp32, the
+    gradients in relative L2."""
+    from contrastyou.arch import UNet
+    from deepclustering2.loss import KL_div
+    from deepclustering2.optim import Adam
+    from semi_seg._utils import IICLossWrapper, ProjectorWrapper
+    from semi_seg.epocher import UDAIICEpocher
+    from itertools import chain
+    from miseg_amd import ops as _ops, unet_ops
+    o = _cfg2_oracle()
+    H, LB, UB = 256, 16, 16
+    model = UNet(1, 4, compute_dtype=dtype)
+    model.load_state_dict(OU.init_state(1, 4, seed=40))
+    pw = ProjectorWrapper()
+    pw.init_encoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
+    pw.init_decoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
+    pw._encoder_projectors["Conv5"].load_state_dict(o["heads"]["Conv5"])
+    pw._decoder_projectors["Up_conv3"].load_state_dict(o["heads"]["Up_conv3"])
+    pw._decoder_projectors["Up_conv2"].load_state_dict(o["heads"]["Up_conv2"])
+    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=1024)
+    model, pw = model.to(DEV), pw.to(DEV)
+    opt = Adam(chain(model.parameters(), pw.parameters()), lr=1e-3, weight_decay=1e-5)
+
+    def loader(img, tgt):
+        B = img.shape[0]
+        yield [[[img, tgt], [img.clone(), tgt.clone()]], [f"patient{j:03d}_00_{j}" for j in range(B)], ["0"] * B, [f"patient{j:03d}_00" for j in range(B)]]
+
+    grabbed, real = [], unet_ops.adam_step
+
+    def spy(param, grad, *a, **k):
+        grabbed.append(grad.detach().clone())
+        return real(param, grad, *a, **k)
+    monkeypatch.setattr(unet_ops, "adam_step", spy)
+    _ops.set_mi_precision(mi_precision)
+    try:
+        random.seed(2468)
+        res = UDAIICEpocher(model, pw, opt, loader(o["limg"], o["ltgt"]), loader(o["uimg"], torch.zeros(UB, 1, H, H, dtype=torch.long)),
+                            KL_div(verbose=False), torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0, device=DEV, feature_position=FEATURES,
+                            feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1).run()
+    finally:
+        _ops.set_mi_precision("fp32")
+    sc = o["sc"]
+    exact = dtype == "float32"
+    np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5 if exact else 2e-2)
+    np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4 if exact else 0.25)
+    if exact:
+        np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
+        for f in FEATURES:
+            np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
+        np.testing.assert_allclose(res["reg_loss"]["mean"], sc["reg_loss"], rtol=2e-4, atol=1e-7)
+    else:
+        assert abs(res["mi"]["mean"] - sc["mi"]) < 0.5 * abs(sc["mi"]) + 1e-4
+    flat, fb = grabbed[0].cpu() / float(opt.grad_scale), opt.flat
+    pref = {"Conv5": pw._encoder_projectors["Conv5"], "Up_conv3": pw._decoder_projectors["Up_conv3"], "Up_conv2": pw._decoder_projectors["Up_conv2"]}
+    worst = {}
+    for name, g_ref in o["grads"].items():
+        if "/" in name:
+            f, k = name.split("/", 1)
+            p = dict(pref[f].named_parameters())[k]
+        elif name.startswith("DeConv_1x1"):
+            p = dict(model.named_parameters())[name]
+        else:
+            continue
+        off = fb.offset_of(p)
+        mine, ref = flat[off:off + p.numel()].view(p.shape).double(), g_ref.double()
+        if float(ref.abs().max()) > 1e-7:
+            worst[name] = float((mine - ref).norm() / ref.norm())
+    _dump(f"cfg2shape_{dtype}_{mi_precision}", {k: (v, v, 0.0) for k, v in worst.items()})
+    dec = {k: v for k, v in worst.items() if not k.startswith("Conv5/")}
+    assert len(dec) >= 2 + 2 * 2                                   # logits layer (weight, bias) + the two decoder heads' parameters
+    if exact:      # measured: logits layer < 1e-7, decoder-tap heads 4e-6 .. 7e-4
+        assert max(dec.values()) < 2e-3, {k: v for k, v in dec.items() if v >= 2e-3}
+        assert max(v for k, v in dec.items() if k.startswith("DeConv_1x1")) < 1e-5, dec
+        assert all(v < 2e-2 for k, v in worst.items() if k.startswith("Conv5/")), worst
+    else:       # bf16 features / logits: the layers next to the losses stay within bf16 forward rounding of the fp32 gradients
+        # measured (round 3, both matrix-core forms alike): logits layer 1.5e-3 / 9e-4, decoder-tap heads 5e-4 .. 6e-3
+        assert max(v for k, v in dec.items() if k.startswith("DeConv_1x1")) < 5e-3, dec
+        assert max(dec.values()) < 2e-2, {k: v for k, v in dec.items() if v >= 2e-2}

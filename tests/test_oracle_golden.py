@@ -275,14 +275,16 @@ def ref_param_name(oracle_name):
     return "proj/" + REF_HEAD_PREFIX[f] + k
 
 
-@pytest.mark.parametrize("mode", ["udaiic", "partial"])
+@pytest.mark.parametrize("mode", ["udaiic", "partial", "uda", "iic"])
 def test_full_step(golden, mode):
-    """Two optimiser steps of the reference's UDAIICEpocher / TrainEpocher vs the oracle restatement:
-    every meter, every parameter gradient of step 1, every parameter after step 2."""
+    """Two optimiser steps of the reference's UDAIICEpocher / TrainEpocher / UDATrainEpocher / IICTrainEpocher
+    (semi_seg/epocher.py:110-323) vs the oracle restatement: every meter, every parameter gradient of step 1, every parameter
+    after step 2."""
     g = golden("step")
     model_sd, heads, lab, unl = step_inputs(mode)
-    state = OS.StepState(model_sd, heads if mode == "udaiic" else {}, lr=STEP["lr"], weight_decay=STEP["wd"])
-    if mode == "partial":
+    has_heads = mode in ("udaiic", "iic")
+    state = OS.StepState(model_sd, heads if has_heads else {}, lr=STEP["lr"], weight_decay=STEP["wd"])
+    if not has_heads:
         state.heads = {}
     seeds = [int(s) for s in g[f"{mode}/seeds"]]
     import random
@@ -303,8 +305,9 @@ def test_full_step(golden, mode):
     np.testing.assert_allclose(mean("reg_loss"), ref["reg_loss/mean"], rtol=1e-4, atol=1e-7)
     for k, v in dice.summary().items():
         np.testing.assert_allclose(v, ref[f"sup_dice/{k}"], rtol=1e-6)
-    if mode == "udaiic":
+    if mode in ("udaiic", "uda"):
         np.testing.assert_allclose(mean("uda"), ref["uda/mean"], rtol=1e-4)
+    if mode in ("udaiic", "iic"):
         np.testing.assert_allclose(mean("mi"), ref["mi/mean"], rtol=1e-3, atol=2e-6)
         for f in ("Conv5", "Up_conv3", "Up_conv2"):
             np.testing.assert_allclose(mean(f"mi/{f}"), ref[f"individual_mis/{f}"], rtol=1e-3, atol=2e-6)
