@@ -353,6 +353,11 @@ int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float*
 int miseg_adam_step_guarded(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale,
                             const float* guard, int64_t nguard);
+/* Overflow test of the half-precision modes (BASELINE configs[4]: torch.cuda.amp-style loss scaling; the reference itself trains in
+ * fp32 and has no such step): count[0] = number of non-finite entries of grad[0..numel), as a float (0 = clean).  The caller appends
+ * it to the guard flags of miseg_adam_step_guarded -- an overflowed gradient then moves neither parameters nor moments -- and the
+ * host lowers the loss scale when the count arrives with the iteration's scalars. */
+int miseg_count_nonfinite(void* stream, const float* grad, int64_t numel, float* count);
 
 /* ------------------------------------------------------------------------------------------
  * Device input pipeline   ref: semi_seg/augment.py:7-52 (ACDCStrongTransforms),

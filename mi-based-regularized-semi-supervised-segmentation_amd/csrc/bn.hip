@@ -543,6 +543,24 @@ extern "C" int miseg_adam_step_guarded(void* stream, float* param, const float* 
     MISEG_LAUNCH_CHECK("adam_kernel");
     return MISEG_OK;
 }
+namespace miseg {
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ count) {
+    int bad = 0;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad += !(fabsf(g[i]) <= 3.4028234e38f);   // inf or NaN
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, (float)bad);       // integers below 2^24: exact in any order
+}
+}  // namespace miseg
+
+extern "C" int miseg_count_nonfinite(void* stream, const float* grad, int64_t numel, float* count) {
+    MISEG_REQUIRE(grad && count && numel > 0, "count_nonfinite: bad args");
+    hipMemsetAsync(count, 0, sizeof(float), as_stream(stream));
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)std::min<int64_t>(cdiv(numel, 1024), 1024)), dim3(256), 0, as_stream(stream), grad, numel, count);
+    MISEG_LAUNCH_CHECK("count_nonfinite_kernel");
+    return MISEG_OK;
+}
+
 extern "C" int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                                       float beta1, float beta2, const float* hyper, float grad_scale) {
     return miseg_adam_step_guarded(stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, grad_scale, nullptr, 0);

@@ -128,6 +128,35 @@ class FlatBuffers:
                 p.grad = slot
 
 
+class LossScaler:
+    """Dynamic loss scale of the half-precision storage mode (BASELINE configs[4]), torch.cuda.amp.GradScaler's policy without its
+    host synchronisation: the device counts the non-finite entries of the flat gradient (``miseg_count_nonfinite``), that count is
+    one more guard flag of the fused Adam launch -- an overflowed gradient moves neither weights nor moments -- and it reaches the
+    host with the iteration's scalars, one iteration late, where ``update`` halves the scale (down to 1) or, after
+    ``growth_interval`` clean iterations in a row, doubles it (up to ``max_scale``)."""
+
+    def __init__(self, init_scale: float, growth_interval: int = 2000, max_scale: float = 65536.0):
+        self.scale, self.growth_interval, self.max_scale = float(init_scale), int(growth_interval), float(max_scale)
+        self.good, self.overflows = 0, 0
+
+    def update(self, nonfinite: float) -> None:
+        if nonfinite != 0.0 or nonfinite != nonfinite:
+            self.overflows += 1
+            self.good = 0
+            self.scale = max(1.0, self.scale * 0.5)
+        else:
+            self.good += 1
+            if self.good >= self.growth_interval:
+                self.good = 0
+                self.scale = min(self.max_scale, self.scale * 2.0)
+
+    def state_dict(self) -> dict:
+        return {"scale": self.scale, "good": self.good, "overflows": self.overflows}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.scale, self.good, self.overflows = float(sd["scale"]), int(sd["good"]), int(sd.get("overflows", 0))
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (amsgrad=False) as one fused HIP launch over flat buffers."""
 
@@ -146,7 +175,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper: List[Optional[Tensor]] = [None] * len(self.param_groups)
         self._hyper_host: List[Optional[Tensor]] = []
         self._pending_state: Optional[dict] = None
-        self.grad_scale = 1.0   # gradients arrive multiplied by this (static loss scale of the fp16 mode); divided out in the kernel
+        self.grad_scale = 1.0   # gradients arrive multiplied by this (loss scale of the fp16 mode); divided out in the kernel
+        self.loss_scaler: Optional[LossScaler] = None      # set by the train epocher in the fp16 storage mode
+        self.last_nonfinite: Optional[Tensor] = None       # device float[1] of the latest ``apply`` in that mode
 
     @property
     def flat(self) -> FlatBuffers:
@@ -198,10 +229,16 @@ class FusedAdam(torch.optim.Optimizer):
     def apply(self, guard: Optional[Tensor] = None) -> None:
         """Device half: gather stray gradients into the flat buffer and launch the fused Adam kernel (a no-op on the device if any
         of the fp32 flags in ``guard`` is set)."""
+        self.last_nonfinite = None
         for gi, group in enumerate(self.param_groups):
             fb = self._flats[gi]
             b1, b2 = group["betas"]
             fb.collect()
+            if self.loss_scaler is not None and fb.flat_grad.is_cuda:
+                # half-precision storage: a gradient that left half's range is inf / NaN here -- count, and let the count guard the update
+                bad = unet_ops.count_nonfinite(fb.flat_grad)
+                self.last_nonfinite = bad if self.last_nonfinite is None else self.last_nonfinite + bad
+                guard = bad if guard is None else torch.cat([guard.reshape(-1), bad])
             unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], self._hyper[gi], b1, b2, self.grad_scale, guard)
         unet_ops.PACK_CACHE.invalidate()   # the fp32 masters changed: packed operand copies are stale
 

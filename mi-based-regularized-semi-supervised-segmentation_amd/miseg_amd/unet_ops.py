@@ -78,9 +78,10 @@ SYNC_COUNTERS = _SyncCounters()
 
 
 def loss_scale_of(model) -> float:
-    """Static loss scale of a model: 1 unless its activations are stored as IEEE half, whose range (6e-8 .. 65504) does not hold the
+    """INITIAL loss scale of a model: 1 unless its activations are stored as IEEE half, whose range (6e-8 .. 65504) does not hold the
     per-pixel gradients of a mean over 48 x 256 x 256 positions (~3e-7).  ``MISEG_LOSS_SCALE`` overrides the default 2^14; the
-    fused Adam divides it back out (``miseg_adam_step_scaled``), so the update equals the unscaled one up to rounding."""
+    fused Adam divides it back out (``miseg_adam_step_scaled``), so the update equals the unscaled one up to rounding.  From there the
+    scale is dynamic (``flat.LossScaler``: halved when the flat gradient holds an inf / NaN, that step skipped on the device)."""
     net = getattr(model, "module", model)
     if getattr(net, "compute_dtype", None) != torch.float16:
         return 1.0
@@ -376,6 +377,15 @@ class _Conv1x1(torch.autograd.Function):
 
 def conv1x1(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return _Conv1x1.apply(x, weight, bias)
+
+
+def count_nonfinite(grad: Tensor) -> Tensor:
+    """Device float[1]: how many entries of the fp32 tensor ``grad`` are inf or NaN (``miseg_count_nonfinite``)."""
+    _need_gpu(grad)
+    assert grad.dtype == torch.float32 and grad.is_contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=grad.device)
+    call("miseg_count_nonfinite", _stream(), _ptr(grad), grad.numel(), _ptr(out))
+    return out
 
 
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, hyper: Tensor, beta1: float, beta2: float,

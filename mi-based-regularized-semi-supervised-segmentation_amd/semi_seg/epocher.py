@@ -318,6 +318,8 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         """Replay the device half of the iteration as one hipGraph (miseg_amd.graph.StepGraph): the ~560 launches of a
         step then cost the host one call.  Single-GPU only; data-parallel runs (a GradReducer is attached) stay eager."""
         from miseg_amd.graph import StepGraph
+        if unet_ops.loss_scale_of(self._model) != 1.0:
+            return          # fp16 storage mode: the loss scale is dynamic (a constant inside a captured step) -> stays eager
         self._step_graph = StepGraph(self, warmup=warmup)
 
     def _device_step(self, labeled_image: Tensor, labeled_target: Tensor, unlabeled_image: Tensor, flips2: Tensor, seed: int):
@@ -356,9 +358,14 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             self._reducer.prepare()
         scale = unet_ops.loss_scale_of(self._model)
         if scale != 1.0:
-            # fp16 storage mode: seed backward with the static loss scale; the fused Adam reads the gradients as grad / scale
+            # fp16 storage mode: seed backward with the loss scale; the fused Adam reads the gradients as grad / scale, counts their
+            # non-finite entries and skips the update if there are any; the scale follows (flat.LossScaler, one iteration late)
             if not hasattr(self._optimizer, "grad_scale"):
                 raise RuntimeError("Arch.compute_dtype=float16 needs the fused Adam (Optim.name=Adam), which undoes the loss scale")
+            if self._optimizer.loss_scaler is None:
+                from miseg_amd.flat import LossScaler
+                self._optimizer.loss_scaler = LossScaler(scale)
+            scale = self._optimizer.loss_scaler.scale
             self._optimizer.grad_scale = scale
             (total_loss * scale).backward()
         else:
@@ -377,6 +384,7 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             self._optimizer.step()
         with torch.no_grad():
             _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False)
+        self._overflow = getattr(self._optimizer, "last_nonfinite", None)     # device float[1] in the fp16 mode, else None
         return inter, union
 
     def _run(self, *args, **kwargs) -> EpochResultDict:
@@ -401,8 +409,11 @@ class TrainEpocher(_num_class_mixin, _Epocher):
     _DEFER_FETCH = os.environ.get("MISEG_DEFER_FETCH", "1") != "0"
     _inflight = None
 
+    _overflow = None
+
     def _after_step(self, inter: Tensor, union: Tensor, label_group) -> None:
-        prev, self._inflight = self._inflight, (self._pending.post((inter, union)), label_group)
+        extras = (inter, union) if self._overflow is None else (inter, union, self._overflow)
+        prev, self._inflight = self._inflight, (self._pending.post(extras), label_group)
         if not self._DEFER_FETCH:
             self._flush_records()
         elif prev is not None:
@@ -414,7 +425,15 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             self._record_ticket(*last)
 
     def _record_ticket(self, ticket, label_group) -> None:
-        host, (inter, union) = self._pending.wait(ticket)
+        host, extras = self._pending.wait(ticket)
+        inter, union = extras[0], extras[1]
+        if len(extras) > 2:         # fp16 mode: the gradient's non-finite count -> the loss scale of the iterations still to be enqueued
+            scaler = self._optimizer.loss_scaler
+            before = scaler.scale
+            scaler.update(float(extras[2][0]))
+            if scaler.scale < before:
+                import warnings
+                warnings.warn(f"fp16 gradient overflow: that optimiser step was skipped, loss scale {before:g} -> {scaler.scale:g}")
         self._record(host, inter.clone(), union.clone(), label_group)   # the meters keep them; the pinned ring is reused
 
     def _record(self, host: dict, inter: Tensor, union: Tensor, label_group) -> None:

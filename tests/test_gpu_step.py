@@ -651,3 +651,62 @@ def test_whole_step_at_the_bench_shape_matches_the_oracle(monkeypatch, dtype, mi
         # measured (round 3, both matrix-core forms alike): logits layer 1.5e-3 / 9e-4, decoder-tap heads 5e-4 .. 6e-3
         assert max(v for k, v in dec.items() if k.startswith("DeConv_1x1")) < 5e-3, dec
         assert max(dec.values()) < 2e-2, {k: v for k, v in dec.items() if v >= 2e-2}
+
+
+def test_count_nonfinite_guards_the_fused_adam():
+    """`miseg_count_nonfinite` + the guard of `miseg_adam_step_guarded`: a flat gradient with one inf (or NaN) leaves parameters and both
+    moments bit-identical; a clean one is counted as 0 and steps."""
+    from miseg_amd import unet_ops
+    g = torch.Generator().manual_seed(3)
+    n = 100_003
+    p0 = torch.randn(n, generator=g).to(DEV)
+    grad = torch.randn(n, generator=g).to(DEV)
+    hyper = torch.tensor([1e-3, 1.0, 1e-8, 1e-5], device=DEV)
+    for poison in (None, float("inf"), float("-inf"), float("nan")):
+        p, m, v, gr = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), grad.clone()
+        if poison is not None:
+            gr[n - 7] = poison
+            gr[5] = poison
+        bad = unet_ops.count_nonfinite(gr)
+        unet_ops.adam_step(p, gr, m, v, hyper, 0.9, 0.999, 1.0, bad)
+        assert float(bad) == (0.0 if poison is None else 2.0)
+        if poison is None:
+            assert not torch.equal(p, p0) and float(m.abs().max()) > 0
+        else:
+            assert torch.equal(p, p0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0
+
+
+def test_fp16_overflow_skips_the_step_and_halves_the_loss_scale(monkeypatch):
+    """BASELINE configs[4]'s arithmetic (IEEE-half storage) with an absurd initial loss scale (2^40: every activation gradient leaves
+    half's range): the overflow count guards the fused Adam on the device -- no weight, no moment moves -- and the scale follows one
+    iteration late (flat.LossScaler): three iterations -> three overflows seen, scale 2^37.  With the default scale the same three
+    iterations are clean and move the weights."""
+    import warnings
+    from semi_seg.epocher import UDAIICEpocher
+    for init, expect_overflows in ((2.0 ** 40, 3), (None, 0)):
+        if init is not None:
+            monkeypatch.setenv("MISEG_LOSS_SCALE", repr(init))
+        else:
+            monkeypatch.delenv("MISEG_LOSS_SCALE", raising=False)
+        STEP3 = dict(STEP)
+        model, pw, lw, opt, lab, unl, kl = build("udaiic", "float16")
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+        def cyc(gen):
+            items = list(gen)
+            while True:
+                yield from items
+        random.seed(99)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            UDAIICEpocher(model, pw, opt, cyc(lab), cyc(unl), kl, torch.nn.MSELoss(), lw, num_batches=3, cur_epoch=0, device=DEV,
+                          feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1).run()
+        sc = opt.loss_scaler
+        assert sc is not None and sc.overflows == expect_overflows, (sc.overflows, sc.scale)
+        moved = any(not torch.equal(before[k], v) for k, v in model.state_dict().items() if k.endswith("weight"))
+        if expect_overflows:
+            assert sc.scale == init / 8 and not moved
+            assert any("overflow" in str(w.message) for w in caught)
+            assert all(float(m.abs().max()) == 0 for m in opt._m)            # the moments did not move either
+        else:
+            assert sc.scale == 16384.0 and moved and sc.good == 3
