@@ -37,7 +37,7 @@ PEAK = {"mfma_bf16": 2500.0, "mfma_f32": 157.3, "hbm": 8000.0}  # TFLOP/s, TFLOP
 MICROBENCH_SUSTAINED = {"bf16": [1824, 1999], "bf16x3": [1822, 2006], "f16f8": [2856, 3118]}
 
 
-def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
+def build_step(device, lb, ub, size, dtype, rank, data="synthetic", classes=4, patch=1024):
     from itertools import chain
 
     from contrastyou.arch import UNet
@@ -47,11 +47,11 @@ def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
     from semi_seg.epocher import UDAIICEpocher
     from semi_seg.synthetic import SyntheticPairs
     torch.manual_seed(0)  # identical initial weights on every rank
-    model = UNet(input_dim=1, num_classes=4, compute_dtype=dtype)
+    model = UNet(input_dim=1, num_classes=classes, compute_dtype=dtype)
     pw = ProjectorWrapper()
     pw.init_encoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
     pw.init_decoder(feature_names=FEATURES, num_clusters=20, num_subheads=5, head_types="linear", normalize=False)
-    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=1024)
+    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=patch)
     model, pw = model.to(device), pw.to(device)
     opt = Adam(chain(model.parameters(), pw.parameters()), lr=1e-7 * 400, weight_decay=1e-5)
     torch.manual_seed(rank), random.seed(rank)
@@ -69,8 +69,8 @@ def build_step(device, lb, ub, size, dtype, rank, data="synthetic"):
         lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=None)
         unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=None)
     else:
-        lab = SyntheticPairs(lb, size, 4, seed=2 * rank, device=device)
-        unl = SyntheticPairs(ub, size, 4, seed=2 * rank + 1, device=device)
+        lab = SyntheticPairs(lb, size, classes, seed=2 * rank, device=device)
+        unl = SyntheticPairs(ub, size, classes, seed=2 * rank + 1, device=device)
     ep = UDAIICEpocher(model, pw, opt, iter(lab), iter(unl), KL_div(verbose=False), torch.nn.MSELoss(), lw, num_batches=1, cur_epoch=0,
                        device=device, feature_position=FEATURES, feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1)
     return ep, opt
@@ -145,7 +145,7 @@ def pmc_fields(tag, flops_per_call, lib_version, args, path=None):
         pmc = json.load(open(path or os.path.join(ROOT, "profiles", "r02_pmc.json")))
     except (OSError, ValueError):
         return none
-    if pmc.get("lib_version") != lib_version or not (args.lb == 16 and args.ub == 16 and args.size == 256 and args.dtype == "bfloat16"):
+    if pmc.get("lib_version") != lib_version or not (args.lb == 16 and args.ub == 16 and args.size == 256 and args.dtype == "bfloat16" and getattr(args, "config", "cfg2") == "cfg2"):
         return none
     prefix = PMC_KERNEL.get(tag)
     hit = next((v for k, v in pmc.get("kernels", {}).items() if prefix and k.startswith(prefix)), None)
@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"],
                     help="storage / MFMA operand type of the U-Net and head kernels (float16 = BASELINE configs[4]'s arithmetic: IEEE half, "
                          "static loss scale MISEG_LOSS_SCALE, default 2^14)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4"],
+                    help="BASELINE.json configs[1] (default: 4 classes, 256^2, whole-map local MI) or configs[3] (8 classes, 512^2, local MI over "
+                         "the 7 x 7 grid of overlapping 128^2 patches, +-3 displacement on Up_conv2; --lb / --ub / --size still apply on top)")
     ap.add_argument("--mi-precision", default=None, choices=["fp32", "bf16x3", "f16f8", "bf16"],
                     help="local-MI contraction arithmetic (default: f16f8 with --dtype bfloat16 / float16 -- f16 hi x hi + fp8 cross terms "
                          "where a kernel has that form, the bf16 hi/lo split elsewhere -- and fp32 with --dtype float32)")
@@ -333,7 +336,12 @@ def main():
     ops.set_mi_precision(mi_prec)
     distributed = ddp.init_from_env("nccl")
 
-    ep, opt = build_step(device, args.lb, args.ub, args.size, args.dtype, rank, args.data)
+    classes, patch = 4, 1024
+    if args.config == "cfg4":        # BASELINE.json configs[3]: 512 x 512, 8 classes, 49 overlapping 128 x 128 patches, pad 3 on Up_conv2
+        classes, patch = 8, 128
+        if args.size == 256:
+            args.size = 512
+    ep, opt = build_step(device, args.lb, args.ub, args.size, args.dtype, rank, args.data, classes, patch)
     drv = StepDriver(ep)
     if distributed:
         opt.flat.ensure()
@@ -402,8 +410,11 @@ def main():
             "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype],
             "data": {"synthetic": "synthetic", "host": "synthetic, pinned host batches copied to the device every step (PCIe-inclusive)",
                      "acdc": "synthetic ACDC-format PNG set through the device input pipeline (224^2 crops)"}[args.data],
-            "config": {"workload": f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
-                                   f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])",
+            "config": {"workload": (f"udaiic train step, ACDC-shaped 1x{args.size}x{args.size} 4-class slices, LB=UB={args.lb} per GPU, "
+                                    f"taps Conv5/Up_conv3/Up_conv2, K=20 x 5 sub-heads, paddings [1,3] (BASELINE configs[1])") if args.config == "cfg2" else
+                                   (f"udaiic train step, synthetic 1x{args.size}x{args.size} 8-class slices, LB=UB={args.lb} per GPU, taps Conv5/Up_conv3/"
+                                    f"Up_conv2, K=20 x 5 sub-heads, paddings [1,3], local MI over overlapping 128x128 patches (stride 64: "
+                                    f"{(args.size // 64 - 1) ** 2} windows on Up_conv2) (BASELINE configs[3])"),
                        "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
                        "parallelism": f"dp{world}", "step_graph": bool(use_graph)},
             # what the collective library actually saw (1 / null when this is a single process without torch.distributed)
