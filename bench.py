@@ -129,8 +129,9 @@ def cpu_baseline(threads):
     return out
 
 
-PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r02_pmc.json
-    "iic_local_bwd[p3]": "local_bwd_rows_kernel<20, 3, 3", "iic_local_bwd[p1]": "local_bwd_rows_kernel<20, 1, 3",
+PMC_FILE = "r03_pmc.json"
+PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r03_pmc.json (the shipped arithmetic: --mi-precision f16f8)
+    "iic_local_bwd[p3]": "local_bwd_f8_kernel<20, 3", "iic_local_bwd[p1]": "local_bwd_rows_kernel<20, 1, 3",
     "iic_local_joint_fwd[p3]": "joint_fwd_px_kernel<3, 3>", "iic_local_joint_fwd[p1]": "joint_fwd_px_kernel<1, 3>",
 }
 
@@ -138,14 +139,14 @@ PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r02_pmc.json
 def pmc_fields(tag, flops_per_call, lib_version, args, path=None):
     """traffic (HBM bytes per launch, FETCH_SIZE + WRITE_SIZE), mfma_busy_frac (SQ_VALU_MFMA_BUSY_CYCLES / all SIMD cycles),
     clock_ghz and ceiling_frac = algorithmic flop / flop of the MFMAs the kernel issues (SQ_INSTS_MFMA x flop per instruction): what
-    `frac` would read with the matrix pipe 100 % busy at the clock the peak is quoted for -- bf16x3 issues three MFMAs per
-    algorithmic product and tiles pad.  All null unless profiles/r02_pmc.json was taken on this library version and shape."""
+    `frac` would read with the matrix pipe 100 % busy at the clock the peak is quoted for -- the operand split issues extra MFMAs per
+    algorithmic product (bf16x3: three; f16f8: one f16 + half a block-scaled fp8 one = the pipe time of two) and tiles pad.  All null unless profiles/r03_pmc.json was taken on this library version, shape and arithmetic."""
     none = {"traffic": None, "mfma_busy_frac": None, "ceiling_frac": None, "clock_ghz": None, "pmc_source": None}
     try:
-        pmc = json.load(open(path or os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        pmc = json.load(open(path or os.path.join(ROOT, "profiles", PMC_FILE)))
     except (OSError, ValueError):
         return none
-    if pmc.get("lib_version") != lib_version or not (args.lb == 16 and args.ub == 16 and args.size == 256 and args.dtype == "bfloat16" and getattr(args, "config", "cfg2") == "cfg2"):
+    if pmc.get("lib_version") != lib_version or getattr(args, "mi_precision", None) not in (None, "f16f8") or not (args.lb == 16 and args.ub == 16 and args.size == 256 and args.dtype == "bfloat16" and getattr(args, "config", "cfg2") == "cfg2"):
         return none
     prefix = PMC_KERNEL.get(tag)
     hit = next((v for k, v in pmc.get("kernels", {}).items() if prefix and k.startswith(prefix)), None)
@@ -154,7 +155,7 @@ def pmc_fields(tag, flops_per_call, lib_version, args, path=None):
     issued = hit.get("issued_mfma_flop")
     return {"traffic": hit.get("traffic_bytes_factor1"), "mfma_busy_frac": hit.get("mfma_busy_frac"), "clock_ghz": hit.get("clock_ghz"),
             "ceiling_frac": round(flops_per_call / issued, 4) if issued else None,
-            "pmc_source": f"profiles/r02_pmc.json (rocprofv3 --pmc, library version {lib_version}; bash profiles/collect_pmc.sh)"}
+            "pmc_source": f"profiles/{PMC_FILE} (rocprofv3 --pmc, library version {lib_version}; bash profiles/collect_pmc.sh)"}
 
 
 def input_pipeline_bench(args):
@@ -327,6 +328,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # stdout carries ONE JSON line (rank 0).  RCCL prints its version banner to stdout when the first communicator comes up: from
+    # here on file descriptor 1 is stderr, the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -386,14 +392,30 @@ def main():
         if not use_graph:
             timer = _cabi.KernelTimer(only={table[0][0]})
             _cabi.TIMER = timer
+    if distributed and getattr(ep, "_reducer", None) is not None:
+        ep._reducer.timing = True
+        ep._reducer._wait_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
     t_host = time.perf_counter() - t0   # host-side loop time (each step waits for the PREVIOUS step's scalars, so it tracks the GPU)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0   # this rank alone: its queue drained, before the barrier that waits for the slowest rank
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed {args.steps} steps in {dt:.3f} s (host loop {t_host:.3f} s)")
+    # what each rank saw (N > 1: so that a scaling curve explains itself): its own step time, how long its host spent enqueueing a
+    # step, how long its gradient stream waited for the all-reduces after backward had finished (the EXPOSED collective time)
+    mine = {"rank": rank, "ms_per_step": round(1000.0 * dt_own / args.steps, 3), "host_loop_ms_per_step": round(1000.0 * t_host / args.steps, 3),
+            "allreduce_exposed_ms_per_step": None}
+    if distributed and getattr(ep, "_reducer", None) is not None:
+        ex = ep._reducer.exposed_ms()
+        mine["allreduce_exposed_ms_per_step"] = None if ex is None else round(ex, 4)
+    per_rank = [mine]
+    if distributed:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
     _cabi.TIMER = None
     drv.close()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -420,6 +442,7 @@ def main():
             # what the collective library actually saw (1 / null when this is a single process without torch.distributed)
             "rccl_ranks": torch.distributed.get_world_size() if distributed else 1,
             "backend": torch.distributed.get_backend() if distributed else None,
+            "per_rank": per_rank,
         }
         if table:
             if timer is not None and timer.records:
@@ -456,7 +479,8 @@ def main():
             except AttributeError:
                 cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(min(cores, 16))  # the GPU box gives one GPU's share of host cores (16)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
         torch.distributed.destroy_process_group()
 

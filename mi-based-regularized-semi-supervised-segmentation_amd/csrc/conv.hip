@@ -1033,7 +1033,7 @@ extern "C" int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void
 
 // the persistent streaming kernel serves the HBM-bound bf16 shapes (one channel chunk, enough tiles to fill the chip)
 static bool conv_streams(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W) {
-    return dt == MISEG_BF16 && Cin <= CK && tile_w(W) == 32 && N * cdiv(H, TH) * cdiv(W, 32) >= 512 && !getenv("MISEG_NO_STREAM");
+    return dt == MISEG_BF16 && Cin <= CK && tile_w(W) == 32 && N * cdiv(H, TH) * cdiv(W, 32) >= 512;
 }
 static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
     static const int64_t cap = [] { const char* e = getenv("MISEG_STREAM_BLOCKS"); return e ? atoll(e) : 512LL; }();    // persistent blocks (2 per CU)
@@ -1043,7 +1043,7 @@ static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
 // tile height of the generic kernel (bf16): 8 rows from 64^2 upwards (smaller LDS tile -> two blocks per CU; measured
 // 128^2 64->32: 78 -> 64 us), 16 rows for the small deep layers (32^2: 8-row tiles cost 46 -> 55 us) and for exact fp32
 static int generic_tile_h(int dt, int64_t H, int64_t W) {
-    static const int force = [] { const char* e = getenv("MISEG_CONV_TH"); return e ? atoi(e) : 0; }();
+    const int force = 0;
     if (dt != MISEG_BF16) return 16;
     if (force == 8 || force == 16) return force;
     return H * W >= 64 * 64 ? 8 : 16;
@@ -1225,7 +1225,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
         // channels (256^2 16->16: 125 -> 52 us, 32->16: 129 -> 83, 128^2 16->32: 85 -> 48) and for 32->64 (71 -> 53);
         // from 32->32 up the 32x32-tile kernel's operand reuse wins
         const bool narrow = Cout % 16 == 0 && (std::min(Cin, Cout) <= 16 || (Cin == 32 && Cout == 64));
-        if ((narrow || Cout <= 16) && !getenv("MISEG_WGRAD_NO_C16")) {
+        if (narrow || Cout <= 16) {
             const size_t lbc = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * 16 * 2;
             dim3 gridc(ns, (unsigned)cdiv(Cin, 16), (unsigned)cdiv(Cout, 16));
             hipLaunchKernelGGL(conv3x3_wgrad_bf16_c16_kernel, gridc, dim3(kCT), lbc, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);

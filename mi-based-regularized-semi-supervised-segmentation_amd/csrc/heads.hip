@@ -288,146 +288,7 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_mfma_kernel(const bf16* __
     if (viol && live && nbad) atomicAdd(viol, nbad);
 }
 
-// Backward pass A: dz = p*(g - <g,p>)/T  (written to ws, same [S][M][K][H][W] layout) and
-// gfeat[src[m]][flip(h,w)][c] += sum_{s,k} W[s][k][c] dz[s][k].
-template <typename T>
-__global__ __launch_bounds__(kHT) void head_local_bwd_dz_kernel(int H, int W, int C, const int32_t* __restrict__ src,
-                                                                const int32_t* __restrict__ flips, int M,
-                                                                const float* __restrict__ w, int S, int K, float invT,
-                                                                const float* __restrict__ prob, const float* __restrict__ gprob,
-                                                                float* __restrict__ dz, T* __restrict__ gfeat) {
-    extern __shared__ float zs[];  // [K][kHT] dz of the current sub-head
-    const int tid = threadIdx.x, HW = H * W;
-    const int m = blockIdx.y;
-    const int pix = blockIdx.x * kHT + tid;
-    const bool live = pix < HW;
-    const int h = live ? pix / W : 0, wq = live ? pix % W : 0;
-    const int f = flips ? flips[m] : 0;
-    T* gp = gfeat + ((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C;
-    // gfeat accumulated over sub-heads in registers, 4 channels at a time would need C/4 passes over s;
-    // instead loop channel-chunk outermost only when C is large: here C <= 128 -> keep s outer, c inner,
-    // and accumulate into global once per chunk at the end via a per-thread LDS-free re-loop.
-    for (int s = 0; s < S; ++s) {
-        const size_t base = (((size_t)s * M + m) * K) * HW + pix;
-        float dot = 0.f;
-        for (int k = 0; k < K; ++k) {
-            float p = live ? prob[base + (size_t)k * HW] : 0.f, g = live ? gprob[base + (size_t)k * HW] : 0.f;
-            zs[k * kHT + tid] = p;
-            dot += p * g;
-        }
-        for (int k = 0; k < K; ++k) {
-            float p = zs[k * kHT + tid], g = live ? gprob[base + (size_t)k * HW] : 0.f;
-            float d = p * (g - dot) * invT;
-            zs[k * kHT + tid] = d;
-            if (live) dz[base + (size_t)k * HW] = d;
-        }
-        if (gfeat && live) {
-            const float* ws = w + (size_t)s * K * C;
-            for (int c0 = 0; c0 < C; c0 += 4) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int k = 0; k < K; ++k) {
-                    const float d = zs[k * kHT + tid];
-                    const float* wr = ws + (size_t)k * C + c0;
-                    a0 += wr[0] * d; a1 += wr[1] * d; a2 += wr[2] * d; a3 += wr[3] * d;
-                }
-                gp[c0 + 0] = from_f32<T>(to_f32(gp[c0 + 0]) + a0);
-                gp[c0 + 1] = from_f32<T>(to_f32(gp[c0 + 1]) + a1);
-                gp[c0 + 2] = from_f32<T>(to_f32(gp[c0 + 2]) + a2);
-                gp[c0 + 3] = from_f32<T>(to_f32(gp[c0 + 3]) + a3);
-            }
-        }
-    }
-}
-
-// Backward pass B: gw[(s,k)][c] = sum_{m,pix} dz[s][m][k][pix] * feat[src[m]][flip(pix)][c], gb[(s,k)] = sum dz.
-// fp32 MFMA 16x16x4: rows = (s,k) (S*K padded to 16s), cols = c, reduction = pixels.  Each block
-// reduces a strided set of (m, 64-pixel) chunks and writes one partial; a second kernel sums partials.
-template <typename T>
-__global__ __launch_bounds__(256) void head_local_bwd_w_kernel(const T* __restrict__ feat, int H, int W, int C,
-                                                               const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
-                                                               int M, int S, int K, const float* __restrict__ dz,
-                                                               float* __restrict__ partials, int nblk) {
-    extern __shared__ float sm[];
-    const int R = S * K, RT = (R + 15) / 16, CT = (C + 15) / 16, HW = H * W;
-    const int DZS = 65;                     // dz tile row stride (64 pixels + 1)
-    float* dzs = sm;                        // [RT*16][DZS]
-    float* fs = sm + (size_t)RT * 16 * DZS; // [64][C+1]
-    const int FS = C + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    // wave wv owns row tiles rt = wv, wv+4, ... (<= 4 per wave for R <= 256) x all column tiles (<= 8)
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float gbacc = 0.f;  // thread t < R accumulates gb[t]
-    const int chunksPerM = (HW + 63) / 64;
-    const int64_t nchunks = (int64_t)M * chunksPerM;
-    for (int64_t ch = blockIdx.x; ch < nchunks; ch += nblk) {
-        const int m = ch / chunksPerM, p0 = (ch % chunksPerM) * 64;
-        const int f = flips ? flips[m] : 0;
-        __syncthreads();
-        for (int idx = tid; idx < RT * 16 * 64; idx += 256) {
-            int px = idx & 63, r = idx >> 6;
-            float v = 0.f;
-            if (r < R && p0 + px < HW) {
-                int s = r / K, k = r % K;
-                v = dz[(((size_t)s * M + m) * K + k) * HW + p0 + px];
-            }
-            dzs[r * DZS + px] = v;
-        }
-        for (int idx = tid; idx < 64 * C; idx += 256) {
-            int c = idx % C, px = idx / C;
-            float v = 0.f;
-            if (p0 + px < HW) {
-                int pix = p0 + px, h = pix / W, wq = pix % W;
-                v = to_f32(feat[((size_t)src[m] * HW + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + c]);
-            }
-            fs[px * FS + c] = v;
-        }
-        __syncthreads();
-        if (tid < R) {
-            float a = 0.f;
-            for (int px = 0; px < 64; ++px) a += dzs[tid * DZS + px];
-            gbacc += a;
-        }
-        for (int ks = 0; ks < 64; ks += 4) {
-            float bfr[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) bfr[c] = (c < CT) ? fs[(ks + kq) * FS + min(c * 16 + l15, C - 1)] : 0.f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int rt = wv + 4 * a;
-                if (rt < RT) {
-                    const float av = dzs[(rt * 16 + l15) * DZS + ks + kq];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (c < CT) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfr[c], acc[a][c], 0, 0, 0);
-                }
-            }
-        }
-    }
-    float* out = partials + (size_t)blockIdx.x * (R * C + R);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int rt = wv + 4 * a;
-        if (rt < RT) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < CT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int row = rt * 16 + kq * 4 + r, col = c * 16 + l15;
-                        if (row < R && col < C) out[row * C + col] = acc[a][c][r];
-                    }
-                }
-        }
-    }
-    if (tid < R) out[R * C + tid] = gbacc;
-}
-
-// Fused backward of the local head (replaces the dz + weight-gradient kernel pair and their 2 x 840 MB dz round
-// trip at the cfg2 shape).  One block = one 64-pixel chunk at a time (persistent, strided):
+// Fused backward of the local head (one pass over prob / gprob: no dz tensor in memory).  One block = one 64-pixel chunk at a time (persistent, strided):
 //   phase 1 (VALU, streaming): dz[(s,k)][px] = p*(g - <g,p>)/T from prob/gprob (coalesced along pixels) -> LDS
 //   phase 2 (fp32 MFMA):       gfeat[px][c] = sum_(s,k) dz[(s,k)][px] * W[(s,k)][c]     (M=px, N=c, Kred=S*K)
 //   phase 3 (fp32 MFMA):       gw[(s,k)][c] += sum_px dz[(s,k)][px] * f[px][c]          (M=(s,k), N=c, Kred=px)
@@ -966,12 +827,6 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 using namespace miseg;
 
 template <int C> static size_t head_mfma_lds(int64_t S) { return (size_t)(kHT / 64) * 20 * kHeadZS * 4 + (size_t)S * 3 * 20 * head_mfma_cp<C>() * 2; }
-// MISEG_HEAD_FWD_VALU=1 keeps the register (VALU) kernel for the shipped shapes: the A/B switch of DESIGN.md section 7
-static bool head_fwd_mfma_off() {
-    static const bool off = [] { const char* e = getenv("MISEG_HEAD_FWD_VALU"); return e && e[0] == '1'; }();
-    return off;
-}
-
 extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
                                     int64_t K, float T, float* prob, float simplex_tol, int32_t* simplex_violations) {
@@ -982,7 +837,7 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
     dim3 grid((unsigned)cdiv(H * W, kHT), (unsigned)M);
     size_t ldsb = (size_t)K * kHT * 4;
     hipStream_t st = as_stream(stream);
-    if (dt == MISEG_BF16 && K == 20 && (C == 16 || C == 32) && (H * W) % 4 == 0 && S * K * C <= 3200 && !head_fwd_mfma_off()) {
+    if (dt == MISEG_BF16 && K == 20 && (C == 16 || C == 32) && (H * W) % 4 == 0 && S * K * C <= 3200) {
         const dim3 gridm((unsigned)cdiv(H * W, kHT * 4), (unsigned)M);
         if (C == 32)
             hipLaunchKernelGGL(head_local_fwd_mfma_kernel<32>, gridm, dim3(kHT), head_mfma_lds<32>(S), st, (const bf16*)feat, (int)H, (int)W,
@@ -1018,19 +873,13 @@ extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int6
     return MISEG_OK;
 }
 
-// MISEG_HEAD_BWD_FUSED=1 keeps the block-phased kernel for the 16-channel tap (A/B switch)
-static bool head_bwd_wave_off() {
-    static const bool off = [] { const char* e = getenv("MISEG_HEAD_BWD_FUSED"); return e && e[0] == '1'; }();
-    return off;
-}
-
 static int head_w_blocks(int64_t M, int64_t HW) { return (int)std::min<int64_t>(M * cdiv(HW, 64), 768); }
 
 extern "C" int64_t miseg_head_local_bwd_ws_bytes(int64_t M, int64_t H, int64_t W, int64_t C, int64_t S, int64_t K) {
     return (((int64_t)head_w_blocks(M, H * W) + 1) * (S * K * C + S * K)) * 4;
 }
 
-static bool head_bwd_wave_shape(int dt, int64_t C, int64_t S, int64_t K) { return dt == MISEG_BF16 && K == 20 && C == 16 && S == 5 && !head_bwd_wave_off(); }
+static bool head_bwd_wave_shape(int dt, int64_t C, int64_t S, int64_t K) { return dt == MISEG_BF16 && K == 20 && C == 16 && S == 5; }
 
 extern "C" int64_t miseg_head_local_bwd_acc_supported(int dt, int64_t C, int64_t S, int64_t K) {
     (void)dt; (void)S; (void)K;
@@ -1081,9 +930,8 @@ static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B
         hipFuncSetAttribute((const void*)head_local_bwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
         // one block per CU: alone the kernel runs as fast with 256 blocks as with 768 (it is bound by the p / g read pattern, 256 B
         // per plane and wave, not by occupancy -- DESIGN.md section 7), and the smaller footprint leaves LDS and registers to the
-        // main-stream kernels this side-stream kernel runs next to.  MISEG_HEAD_BWD_BLOCKS overrides (A/B runs).
-        static const int cap = [] { const char* e = getenv("MISEG_HEAD_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
-        const int nb = cap > 0 ? std::min(cap, nblk) : nblk;
+        // main-stream kernels this side-stream kernel runs next to.
+        const int nb = std::min(256, nblk);
         nused = nb;   // the final reduction reads this kernel's nb partials only
         hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nb), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
                            (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials, accumulate);

@@ -784,13 +784,12 @@ extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y,
         b2.N = (int)N; b2.K = (int)K; b2.Kc = ((int)K + 3) & ~3; b2.H = (int)H; b2.W = (int)W; b2.pad = (int)pad; b2.T = 2 * (int)pad + 1;
         b2.P = (int)P; b2.Mdim = b2.T * b2.K; b2.Kred = b2.T * b2.Kc; b2.ksteps = b2.Kred / 4;
         b2.WB = 64 - 2 * b2.pad; b2.RS = 4 + 2 * b2.pad; b2.planeS = (b2.RS * 64) | 1; b2.gstride = b2.Kred | 1; b2.G = 256;
-        { const char* ab = getenv("MISEG_ABLATE"); b2.ablate = ab ? atoi(ab) : 0; }
+        b2.ablate = 0;
         const int mt = (b2.Mdim + 15) / 16;
         const int mtc = mt <= 4 ? 4 : 9;
         const size_t lds2 = ((size_t)mtc * 16 * b2.gstride + (size_t)b2.Kc * b2.planeS + (size_t)4 * b2.K * 68 + (size_t)mtc * 16) * 4;
         b2.accumulate = accumulate;
         b2.plain_rmw = (4 % b2.K != 0) && (8 % b2.K != 0) && (12 % b2.K != 0);
-        if (getenv("MISEG_COL2IM_ATOMIC")) b2.plain_rmw = 0;
         if (mt <= 9 && b2.WB >= 16 && b2.RS <= 10 && b2.Kc <= 20 && lds2 <= (size_t)kLdsBudget) {
             if (mtc == 4) {
                 hipFuncSetAttribute((const void*)local_bwd2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

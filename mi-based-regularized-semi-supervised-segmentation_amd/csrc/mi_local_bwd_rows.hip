@@ -419,31 +419,12 @@ int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_
         nterms = 3;
     }
     RowsGeom g{(int)N, (int)H, (int)W, (int)P, (int)S, accumulate, 256, (long long)hs};
-    // Shape of a block = waves x strip width.  Measured on the cfg2 launch (S=5, N=16, 256^2, pad 3; bench, same box): 12x32 1.14 ms,
-    // 8x32 1.17, 8x64 1.19, 4x64 1.31-1.38 (one wave per SIMD: nothing covers a wave's row-end fetch / split / store phase); the
-    // stacked-(b,o) kernel 1.6.  12x32 = three waves per SIMD, no in-wave prefetch, 155 registers.  MISEG_BWD_ROWS_SHAPE selects.
-    // Since the work is dealt in equal contiguous shares the shapes are within 2 % of each other as kernels (12x32 1.06-1.08 ms, 8x64
-    // 1.07-1.12, 8x32 1.12-1.15, 4x64 1.29-1.31), but the STEP is 0.05-0.06 ms shorter with 8x64 than with 12x32 in three same-box
-    // alternations (7.32-7.36 vs 7.38-7.41 ms: eight waves leave more of the CU to the kernels of the other streams) -- the default.
-    static const int wide = [] { const char* e = getenv("MISEG_BWD_ROWS_SHAPE"); return !e ? 2 : !strcmp(e, "4x64") ? 1 : !strcmp(e, "8x32") ? 0 : !strcmp(e, "8x64") ? 2 : !strcmp(e, "16x32") ? 4 : !strcmp(e, "12x32") ? 3 : 2; }();
-    if (wide == 1) {
-        if (pad == 3) return launch_rows<20, 3, 4, 4>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-        return launch_rows<20, 1, 4, 4>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-    }
-    if (wide == 3) {
-        if (pad == 3) return launch_rows<20, 3, 2, 12>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-        return launch_rows<20, 1, 2, 12>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-    }
-    if (wide == 4) {
-        if (pad == 3) return launch_rows<20, 3, 2, 16>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-        return launch_rows<20, 1, 2, 16>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-    }
-    if (wide == 2) {   // 8 waves x 64-column strips
-        if (pad == 3) return launch_rows<20, 3, 4, 8>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-        return launch_rows<20, 1, 4, 8>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-    }
-    if (pad == 3) return launch_rows<20, 3, 2, 8>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
-    return launch_rows<20, 1, 2, 8>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
+    // Shape of a block = 8 waves x 64-column strips.  Measured on the cfg2 launch (S=5, N=16, 256^2, pad 3; round 2): with the work dealt
+    // in equal contiguous shares the shapes 12x32 / 8x64 / 8x32 / 4x64 are within 2 % of each other as kernels (1.06-1.12 ms; 4x64, one
+    // wave per SIMD, 1.29-1.31), but the STEP is 0.05-0.06 ms shorter with 8x64 than with 12x32 (eight waves leave more of the CU to
+    // the kernels of the other streams).
+    if (pad == 3) return launch_rows<20, 3, 4, 8>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
+    return launch_rows<20, 1, 4, 8>(st, x, y, g, win, grad_raw, scale, gx, gy, ws, nterms);
 }
 
 }  // namespace miseg

@@ -73,6 +73,8 @@ class GradReducer:
         self.producer_streams: list = []   # extra streams that write gradients (see semi_seg.epocher IIC side stream)
         self._handles: List[Optional[object]] = []
         self._armed = False
+        self.timing = False                 # bench.py: record an event pair around finish()'s waits
+        self._wait_events: list = []
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         if broadcast_params:
@@ -115,10 +117,27 @@ class GradReducer:
         for b in range(len(self.buckets)):
             if self._handles[b] is None:  # some parameter of the bucket got no gradient this step
                 self._launch(b)
+        timed = self.timing and self.flat.flat_grad.is_cuda
+        if timed:       # from "this stream has nothing left but to wait for the collectives" to "they are done": the EXPOSED part
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
         if not self._avg_native:
             self.flat.flat_grad.div_(self.world)
+
+    def exposed_ms(self) -> Optional[float]:
+        """Mean device time per step the gradient stream spent waiting for its all-reduces after the backward pass had finished
+        (``timing`` must have been on; synchronises)."""
+        if not self._wait_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._wait_events]
+        self._wait_events = []
+        return sum(ms) / len(ms)
 
 
 def attach(trainer, num_buckets: int = 3) -> Optional[GradReducer]:

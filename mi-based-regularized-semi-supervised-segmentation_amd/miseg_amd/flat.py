@@ -215,15 +215,15 @@ class FusedAdam(torch.optim.Optimizer):
             # the copy engine -- a single slot would be rewritten for step i+2 while step i+1's copy may still be queued.
             while len(self._hyper_host) <= gi:
                 self._hyper_host.append(None)
+            vals = torch.tensor([group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]], dtype=torch.float32)
+            if not self._hyper[gi].is_cuda:
+                self._hyper[gi].copy_(vals)
+                continue
             ring = self._hyper_host[gi]
-            if ring is None or ring.device.type != "cpu":
-                ring = torch.zeros(4, 4, dtype=torch.float32)
-                if self._hyper[gi].is_cuda:
-                    ring = ring.pin_memory()
-                self._hyper_host[gi] = ring
-            host = ring[t % 4]
-            host[0], host[1], host[2], host[3] = group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]
-            self._hyper[gi].copy_(host, non_blocking=True)
+            if ring is None:
+                from .ops import PinnedRing
+                ring = self._hyper_host[gi] = PinnedRing((4,), torch.float32, slots=4)
+            ring.upload_into(lambda slot: slot.copy_(vals), self._hyper[gi])
 
     @torch.no_grad()
     def apply(self, guard: Optional[Tensor] = None) -> None:

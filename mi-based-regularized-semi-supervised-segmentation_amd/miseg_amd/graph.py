@@ -63,10 +63,8 @@ class StepGraph:
         self.s_li.copy_(li, non_blocking=True)
         self.s_lt.copy_(lt, non_blocking=True)
         self.s_ui.copy_(ui, non_blocking=True)
-        self._turn = (getattr(self, "_turn", 0) + 1) % 4      # pinned staging ring: the host may run two steps ahead of the copy engine
-        stage = self.h_masks[self._turn]
-        stage.copy_(torch.tensor(masks, dtype=torch.int32))
-        self.s_masks.copy_(stage, non_blocking=True)
+        # pinned staging ring (the host may run two steps ahead of the copy engine; a slot waits for its own last copy before reuse)
+        self.h_masks.upload_into(lambda slot: slot.copy_(torch.tensor(masks, dtype=torch.int32)), self.s_masks)
         ep._optimizer.advance()
         self.graph.replay()
         unet_ops.PACK_CACHE.invalidate()       # the replay ran Adam: eager users (evaluation) must re-pack
@@ -78,7 +76,8 @@ class StepGraph:
         dev = li.device
         self.s_li, self.s_lt, self.s_ui = li.clone(), lt.clone(), ui.clone()
         self.s_masks = torch.zeros(len(masks), dtype=torch.int32, device=dev)
-        self.h_masks = torch.zeros(4, len(masks), dtype=torch.int32).pin_memory()
+        from .ops import PinnedRing
+        self.h_masks = PinnedRing((len(masks),), torch.int32, slots=4)
         ep._pending.drain()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()

@@ -138,7 +138,7 @@ def evaluate(items: Sequence[Union[LinearLoss, Tensor]], passthrough: Sequence[T
         return out
 
 
-_FUSED_REPORT = __import__("os").environ.get("MISEG_FUSED_REPORT", "1") != "0"     # A/B switch: 0 = the torch-op evaluation on the GPU too
+_FUSED_REPORT = True     # False: the torch-op evaluation on the GPU too (a dozen one-element launches; tests compare the two)
 
 
 def report(items: Sequence[Union[LinearLoss, Tensor]], check_items: Sequence[tuple] = ()) -> Tensor:

@@ -81,6 +81,44 @@ def flips_to_tensor(decisions: Sequence[Sequence[bool]], device) -> Tensor:
     return torch.tensor(flip_masks(decisions), dtype=torch.int32, device=device)
 
 
+
+class PinnedRing:
+    """``slots`` pinned host buffers of one shape used round-robin as the source of non-blocking host->device copies.  Every slot
+    remembers an event recorded behind its last copy and waits for it before the slot is rewritten: free while the host is fewer than
+    ``slots`` copies ahead of the copy engine, and a loop WITHOUT a per-iteration host synchronisation (a user loop, `bench.py
+    --workload input`) can no longer overwrite a slot whose copy is still queued."""
+
+    def __init__(self, shape, dtype, slots: int = 4):
+        self.host = torch.empty((slots,) + tuple(shape), dtype=dtype).pin_memory()
+        self.events = [None] * slots
+        self.turn = 0
+
+    def upload(self, fill, device) -> Tensor:
+        """``fill(host_slot)`` writes the payload; returns a fresh device tensor holding it (copy enqueued on the current stream)."""
+        self.turn = (self.turn + 1) % len(self.events)
+        ev = self.events[self.turn]
+        if ev is not None:
+            ev.synchronize()
+        slot = self.host[self.turn]
+        fill(slot)
+        out = torch.empty(slot.shape, dtype=slot.dtype, device=device)
+        out.copy_(slot, non_blocking=True)
+        ev = self.events[self.turn] = ev or torch.cuda.Event()
+        ev.record()
+        return out
+
+    def upload_into(self, fill, dst: Tensor) -> None:
+        """The same into an existing device tensor (static buffers of a captured step)."""
+        self.turn = (self.turn + 1) % len(self.events)
+        ev = self.events[self.turn]
+        if ev is not None:
+            ev.synchronize()
+        slot = self.host[self.turn]
+        fill(slot)
+        dst.copy_(slot, non_blocking=True)
+        ev = self.events[self.turn] = ev or torch.cuda.Event()
+        ev.record()
+
 # ------------------------------------------------------------------------------------------ local MI
 MI_PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16f8": 3}
 _mi_precision = MI_PRECISIONS.get(__import__("os").environ.get("MISEG_MI_PRECISION", "fp32"), 0)
@@ -775,7 +813,7 @@ def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True
 
 
 # ------------------------------------------------------------------------------------------ split with a layout-preserving backward
-_SPLIT_MEMCPY = __import__("os").environ.get("MISEG_SPLIT_MEMCPY", "0") == "1"   # A/B switch
+_SPLIT_MEMCPY = False   # True: assemble slice gradients with hipMemcpy (slower on a busy device)
 
 
 class _SplitRows(torch.autograd.Function):

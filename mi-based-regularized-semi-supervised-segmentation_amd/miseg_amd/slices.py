@@ -289,15 +289,13 @@ class ResidentSlices:
         # run-ahead x safety): a pageable `.to(device)` is a synchronous copy, i.e. the host would wait for the GPU queue to drain
         # once per batch (semi_seg/epocher.py `_upload_flips` has the measurement)
         jh = torch.from_numpy(np.ascontiguousarray(jobs, dtype=np.int32))
-        ring = self.__dict__.setdefault("_job_ring", {})
+        from .ops import PinnedRing
+        rings = self.__dict__.setdefault("_job_ring", {})
         key = tuple(jh.shape)
-        slot = ring.get(key)
-        if slot is None:
-            slot = ring[key] = [torch.empty((8,) + key, dtype=torch.int32).pin_memory(), 0]
-        slot[1] = (slot[1] + 1) % 8
-        slot[0][slot[1]].copy_(jh)
-        jd = torch.empty(key, dtype=torch.int32, device=self.device)
-        jd.copy_(slot[0][slot[1]], non_blocking=True)
+        ring = rings.get(key)
+        if ring is None:
+            ring = rings[key] = PinnedRing(key, torch.int32, slots=8)
+        jd = ring.upload(lambda slot: slot.copy_(jh), self.device)
         img = torch.empty(n, 1, out_h, out_w, dtype=torch.float32, device=self.device)
         gt = torch.empty(n, 1, out_h, out_w, dtype=torch.int64, device=self.device) if self.gt is not None else None
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -47,7 +47,7 @@ def join_wgrad_streams() -> None:
     _wgrad_dirty.clear()
 
 
-_FUSE_UPS_DGRAD = os.environ.get("MISEG_FUSE_UPS_DGRAD", "1") != "0"   # A/B switch: 0 = conv3x3 dgrad + miseg_sumpool2x2 as two launches
+_FUSE_UPS_DGRAD = True   # False: conv3x3 dgrad + miseg_sumpool2x2 as two launches
 
 
 class _SyncCounters:
@@ -112,7 +112,7 @@ def _pack_now(weight: Tensor, dtype, kind: int, ci_begin: int, ci_count: int, pa
     return packed
 
 
-_NO_PACK_CACHE = __import__("os").environ.get("MISEG_NO_PACK_CACHE", "0") == "1"
+_NO_PACK_CACHE = False
 
 
 class _PackCache:

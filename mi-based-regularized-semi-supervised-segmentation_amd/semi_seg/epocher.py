@@ -296,17 +296,12 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         runs up to two iterations ahead of the copy engine): `torch.tensor(list, device=cuda)` copies from pageable memory, which
         hipMemcpy does synchronously -- the host then waits for the queue to drain at the top of EVERY iteration, and the launches
         of the next step's head are exposed (a replayed step graph, which stages its masks like this, was 0.3 ms ahead of eager)."""
-        if device.type != "cuda" or os.environ.get("MISEG_PINNED_FLIPS", "1") == "0":     # the switch: same-box A/B only
+        if device.type != "cuda":
             return torch.tensor(flip_masks, dtype=torch.int32, device=device)
         ring = self._flip_ring
-        if ring is None or ring[0].shape[1] != len(flip_masks):
-            ring = self._flip_ring = [torch.zeros(4, len(flip_masks), dtype=torch.int32).pin_memory(), 0]
-        ring[1] = (ring[1] + 1) % 4
-        host = ring[0][ring[1]]
-        host.copy_(torch.as_tensor(flip_masks, dtype=torch.int32))
-        out = torch.empty(len(flip_masks), dtype=torch.int32, device=device)
-        out.copy_(host, non_blocking=True)
-        return out
+        if ring is None or ring.host.shape[1] != len(flip_masks):
+            ring = self._flip_ring = ops.PinnedRing((len(flip_masks),), torch.int32, slots=4)
+        return ring.upload(lambda slot: slot.copy_(torch.as_tensor(flip_masks, dtype=torch.int32)), device)
 
     def _before_forward(self, ub: int) -> None:   # hooks for epochers that start work while the network is still running
         pass

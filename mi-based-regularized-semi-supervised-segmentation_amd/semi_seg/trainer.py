@@ -154,9 +154,9 @@ class SemiTrainer(Trainer):
 
     # ------------------------------------------------------------------ inference
     def inference(self, checkpoint=None):  # noqa
-        target = _checkpoint_file(checkpoint, self._save_dir)
         if checkpoint is not None and not Path(checkpoint).exists():
-            raise AssertionError(checkpoint)
+            raise AssertionError(checkpoint)         # the reference asserts the path (semi_seg/trainer.py:112-115) before resolving it
+        target = _checkpoint_file(checkpoint, self._save_dir)
         self.load_state_dict_from_path(str(target), strict=True)
         runner = E.InferenceEpocher(self._model, val_loader=self._test_loader, sup_criterion=self._sup_criterion,
                                     cur_epoch=self._cur_epoch, device=self._device)

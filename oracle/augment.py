@@ -34,18 +34,19 @@ from PIL import Image, ImageEnhance
 
 # ----------------------------------------------------------------------------- seeding (whl decorator.py:196-212)
 class FixRandomSeed:
+    """Seeds `random` and numpy's legacy generator for the block; afterwards both continue from their state at CONSTRUCTION time."""
+
     def __init__(self, random_seed: int = 0):
         self.random_seed = random_seed
-        self.randombackup = random.getstate()
-        self.npbackup = np.random.get_state()
+        self._saved = {"py": random.getstate(), "np": np.random.get_state()}
 
     def __enter__(self):
-        np.random.seed(self.random_seed)
         random.seed(self.random_seed)
+        np.random.seed(self.random_seed)
 
     def __exit__(self, *_):
-        np.random.set_state(self.npbackup)
-        random.setstate(self.randombackup)
+        random.setstate(self._saved["py"])
+        np.random.set_state(self._saved["np"])
 
 
 # ----------------------------------------------------------------------------- torchvision 0.7 functional (restated)

@@ -4,7 +4,7 @@
 # The program itself follows `--` (no env / bash -c hop: the profiler's preloaded library has already initialised the GPU).
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; T=${1:-r02}; O=$R/gpurun_out/pmc_$T; mkdir -p $O
+R=$GRAFT_REPO_ROOT; T=${1:-r03}; O=$R/gpurun_out/pmc_$T; mkdir -p $O
 ARGS="$R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer"
 i=0
 for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \

@@ -3,7 +3,9 @@
 gpurun_out/, untracked).  Derived per kernel:
   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the dispatch), shader cycles = GRBM_GUI_ACTIVE / 8 XCDs
   clock_ghz      = shader cycles / dispatch duration
-  issued_mfma_flop = SQ_INSTS_MFMA x flop of the kernel's MFMA shape (table below)
+  issued_mfma_flop = SQ_VALU_MFMA_BUSY_CYCLES x 1024: the matrix-pipe time of the kernel's MFMAs in bf16-equivalent flop (a 16x16x32
+                     bf16 / f16 MFMA = 16 384 flop holds its SIMD's pipe for 16 cycles; a block-scaled 16x16x128 fp8 one 32) -- for
+                     the single-shape kernels this equals SQ_INSTS_MFMA x flop per instruction (`issued_mfma_flop_by_count`)
 bench.py reads this file for `roofline.mfma_busy_frac` / `ceiling_frac` / `traffic`, keyed by kernel AND library version."""
 import collections
 import csv
@@ -16,7 +18,7 @@ SIMDS, XCDS = 1024, 8
 # flop per MFMA instruction of the shape each kernel family issues (16x16x32 bf16: 2*16*16*32; 32x32x16: 2*32*32*16; 16x16x4 f32: 2*16*16*4)
 MFMA_FLOP = (("local_bwd", 16384), ("joint_fwd", 16384), ("conv3x3_wgrad", 32768), ("conv3x3", 16384), ("head_local_fwd_mfma", 16384),
              ("head_local_bwd_wave", 16384), ("head_local_bwd_fused", 16384))
-FAMILIES = ("local_bwd_rows_kernel", "local_bwd_bf16_kernel", "joint_fwd_bf16_kernel", "joint_fwd_px_kernel", "conv3x3_stream_kernel", "conv3x3_kernel",
+FAMILIES = ("local_bwd_rows_kernel", "local_bwd_f8_kernel", "local_bwd_bf16_kernel", "joint_fwd_bf16_kernel", "joint_fwd_px_kernel", "conv3x3_stream_kernel", "conv3x3_kernel",
             "conv3x3_wgrad_bf16_kernel", "conv3x3_wgrad_c16_kernel", "head_local_fwd_mfma_kernel", "head_local_bwd_wave_kernel",
             "head_local_bwd_fused_kernel", "bn_relu_bwd", "bn_relu_fwd")
 
@@ -56,9 +58,11 @@ def main(src, dst):
             e["clock_ghz"] = round(cyc / e["avg_us_profiled"] / 1e3, 3)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
                 e["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            e["issued_mfma_flop"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] * 1024.0
         for fam, fl in MFMA_FLOP:
-            if fam in k and "SQ_INSTS_MFMA" in m:
-                e["issued_mfma_flop"] = m["SQ_INSTS_MFMA"] * fl
+            if fam in k and "SQ_INSTS_MFMA" in m and "local_bwd_f8" not in k:       # the f8 kernel mixes two shapes
+                e["issued_mfma_flop_by_count"] = m["SQ_INSTS_MFMA"] * fl
                 break
         if "FETCH_SIZE" in m or "WRITE_SIZE" in m:
             e["traffic_bytes_factor1"] = int((m.get("FETCH_SIZE", 0) + m.get("WRITE_SIZE", 0)) * 1000)

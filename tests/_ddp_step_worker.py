@@ -22,8 +22,8 @@ def main():
     data_rank, out, dtype = int(sys.argv[1]), sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "float32")
     _cabi.lib()
     ops.set_mi_precision("fp32" if dtype == "float32" else "bf16x3")
-    distributed = ddp.init_from_env()                 # MISEG_DDP_BACKEND=gloo from the test
-    dev = torch.device("cuda", 0)
+    distributed = ddp.init_from_env()                 # MISEG_DDP_BACKEND=gloo from the one-GPU test, RCCL otherwise
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))     # gloo test: both ranks on cuda:0; RCCL test: one GPU each
     ep, opt = bench.build_step(dev, 2, 3, 64, dtype, data_rank)     # weights: seed 0 on every rank; data: seeded by data_rank
     drv = bench.StepDriver(ep)
     if distributed:

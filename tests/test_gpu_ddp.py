@@ -49,3 +49,28 @@ def test_two_rank_step_reduces_to_the_mean_of_the_shard_gradients(tmp_path, dtyp
     scale = float(mean.abs().max())
     assert err <= 2e-6 * scale, (err, scale)
     assert float((singles[0]["grad"] - singles[1]["grad"]).abs().max()) > 1e-3 * scale     # the shards really differ
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: the test box has a single GPU (the driver's 8-GPU node runs it)")
+def test_two_rank_step_over_rccl(tmp_path):
+    """The same two-rank step over the `nccl` backend (= RCCL on ROCm), one GPU per rank: bucketed asynchronous all-reduce (native AVG)
+    from the autograd hooks on the collective's own stream, joined by `GradReducer.finish`.  Skips below two visible GPUs."""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MISEG_DDP_BACKEND")}
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    singles = []
+    for r in range(2):
+        p = _run([r, tmp_path / f"single{r}.pt", "bfloat16"], env=base)
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+        singles.append(torch.load(tmp_path / f"single{r}.pt"))
+    port = 34500 + os.getpid() % 2000
+    procs = [_run([r, tmp_path / f"rccl{r}.pt", "bfloat16"],
+                  env=dict(base, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    d0, d1 = (torch.load(tmp_path / f"rccl{r}.pt") for r in range(2))
+    assert d0["buckets"] == 3 and torch.equal(d0["grad"], d1["grad"]) and torch.equal(d0["param_after"], d1["param_after"])
+    mean = (singles[0]["grad"].double() + singles[1]["grad"].double()) / 2
+    err, scale = float((d0["grad"].double() - mean).abs().max()), float(mean.abs().max())
+    assert err <= 2e-6 * scale, (err, scale)

@@ -717,10 +717,13 @@ _CFG4_ORACLE = {}
 
 @pytest.mark.parametrize("dtype,mi_precision", [("float32", "fp32"), ("bfloat16", "f16f8")])
 def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
-    """BASELINE configs[3] as a whole step at reduced batch: 512 x 512 slices, EIGHT classes, local MI over the 7 x 7 grid of
-    overlapping 128 x 128 patches (49 windows, +-3 displacement on Up_conv2, +-1 on Up_conv3; ref iic_loss.py:152-189) -- one
-    `udaiic` iteration with LB = UB = 1 against the CPU oracle on the same weights: every meter, the gradients of the logits layer and
-    of the head parameters.  (`python bench.py --config cfg4` times the same configuration at LB = UB = 16.)"""
+    """BASELINE configs[3] as a whole step, reduced to what the CPU oracle finishes in a minute: EIGHT classes, local MI over the
+    7 x 7 grid of half-overlapping patches (49 windows, +-3 displacement on Up_conv2, +-1 on Up_conv3; ref iic_loss.py:152-189) on
+    256 x 256 slices with 64 x 64 patches (configs[3] itself: 512 x 512 with 128 x 128 patches -- the same grid at twice the scale;
+    its local-MI launches at full size are checked in test_gpu_mi.py::test_patch_local_mi / test_bf16x3_batched_heads_with_
+    overlapping_patches / test_joint_checksum_at_full_size, and `python bench.py --config cfg4` times it at LB = UB = 16) -- one
+    `udaiic` iteration with LB = UB = 1 against the oracle on the same weights: every meter, the gradients of the logits layer and
+    of the head parameters."""
     from oracle import step as OS
     from contrastyou.arch import UNet
     from deepclustering2.loss import KL_div
@@ -729,7 +732,7 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
     from semi_seg.epocher import UDAIICEpocher
     from itertools import chain
     from miseg_amd import ops as _ops, unet_ops
-    H, LB, UB, NC = 512, 1, 1, 8
+    H, LB, UB, NC, PATCH = 256, 1, 1, 8, 64
     heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=51), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=52),
              "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=53)}
     limg, ltgt = T(synth.uniform("cfg4step/lab", (LB, 1, H, H))), T(synth.integers("cfg4step/tgt", (LB, 1, H, H), NC))
@@ -742,7 +745,7 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
     pw._encoder_projectors["Conv5"].load_state_dict(heads["Conv5"])
     pw._decoder_projectors["Up_conv3"].load_state_dict(heads["Up_conv3"])
     pw._decoder_projectors["Up_conv2"].load_state_dict(heads["Up_conv2"])
-    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=128)
+    lw = IICLossWrapper(feature_names=FEATURES, paddings=[1, 3], patch_sizes=PATCH)
     model, pw = model.to(DEV), pw.to(DEV)
     opt = Adam(chain(model.parameters(), pw.parameters()), lr=1e-3, weight_decay=1e-5)
 
@@ -764,7 +767,7 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
                             feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1).run()
     finally:
         _ops.set_mi_precision("fp32")
-    if not _CFG4_ORACLE:        # one oracle step (~2.5 min of CPU) shared by the two parametrisations
+    if not _CFG4_ORACLE:        # one oracle step (~1 min of CPU) shared by the two parametrisations
         random.seed(1357)
         seed = random.randint(0, int(1e7))
         state = OS.StepState(OU.init_state(1, NC, seed=50), heads, lr=1e-3, weight_decay=1e-5)
@@ -772,7 +775,7 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
         torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
         try:
             _CFG4_ORACLE["sc"], _CFG4_ORACLE["grads"] = OS.train_step(
-                state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], paddings=[1, 3], patch_sizes=[128, 128],
+                state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], paddings=[1, 3], patch_sizes=[PATCH, PATCH],
                 cons_weight=5.0, iic_weight=0.1, num_classes=NC, do_update=False)
         finally:
             torch.set_num_threads(threads)
