@@ -86,17 +86,18 @@ struct Rows8Geom {
 };
 
 // 2^floor(log2 max|G|) per (sub-head, window): the exponent f16 needs taken out of G
-__global__ __launch_bounds__(256) void gexp_kernel(const float* __restrict__ grad_raw, int per, float* __restrict__ gexp) {
+__global__ __launch_bounds__(1024) void gexp_kernel(const float* __restrict__ grad_raw, int per, float* __restrict__ gexp) {
     const float* G = grad_raw + (size_t)blockIdx.x * per;
     float m = 0.f;
-    for (int e = threadIdx.x; e < per; e += 256) m = fmaxf(m, fabsf(G[e]));
+    for (int e = threadIdx.x; e < per; e += 1024) m = fmaxf(m, fabsf(G[e]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float red[4];
+    __shared__ float red[16];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
         gexp[blockIdx.x] = (m > 0.f && m < 3.0e38f) ? ldexpf(1.f, ilogbf(m)) : 1.f;
     }
 }
@@ -420,30 +421,43 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
 #undef MISEG_ROWS8_CASE
                 default: break;
             }
-            auto put = [&](float v, unsigned voff, unsigned soff) {
-#if MISEG_F8_ABL & 2
-                if (v != 1234.5f) return;
-#endif
-                if (ACC) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)voff, (int)soff, 0));
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)voff, (int)soff, 0);
-            };
+            // Store (or, for windows that share pixels with windows of earlier launches, add into) the finished row.  The accumulate form
+            // issues ALL its loads before the first store: a load / add / store chain per element serialises on the memory round trip
+            // (the compiler may not move a load above a store to the same buffer) -- 48 round trips per row and wave made the 49-window
+            // launches of BASELINE configs[3] take 6.3 ms instead of 3.
             const unsigned qplane = (unsigned)(4 * q) * (unsigned)plane * 4u;
+            unsigned vo_m[NT], vo_r[RT][NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned vo = (keep && col0 + nt * 16 + l15 < w1w) ? qplane + (unsigned)(nt * 16 + l15) * 4u : OOB;
+                const bool cok = keep && col0 + nt * 16 + l15 < w1w;
+                vo_m[nt] = cok ? qplane + (unsigned)(nt * 16 + l15) * 4u : OOB;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) put(sc * done[nt][r], vo, rowo + (unsigned)r * (unsigned)plane * 4u);
+                for (int t = 0; t < RT; ++t) vo_r[t][nt] = (cok && t * 4 + q == jdone) ? (unsigned)(nt * 16 + l15) * 4u : OOB;
+            }
+            float old_m[NT][4], old_r[RT][NT][4];
+            if (ACC) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        old_m[nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)vo_m[nt], (int)(rowo + (unsigned)r * (unsigned)plane * 4u), 0));
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            old_r[t][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), 0));
+                    }
             }
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const bool mine = t * 4 + q == jdone;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned vo = (keep && mine && col0 + nt * 16 + l15 < w1w) ? (unsigned)(nt * 16 + l15) * 4u : OOB;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = sc * done[nt][r] + (ACC ? old_m[nt][r] : 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)vo_m[nt], (int)(rowo + (unsigned)r * (unsigned)plane * 4u), 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) put(sc * rem[t][nt][r], vo, rowo + (unsigned)(16 + r) * (unsigned)plane * 4u);
+                    for (int t = 0; t < RT; ++t) {
+                        const float vr = sc * rem[t][nt][r] + (ACC ? old_r[t][nt][r] : 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), 0);
+                    }
                 }
-            }
 #if !(MISEG_F8_ABL & 1)
             if (hsr < hs_last) {
                 fetch_row(hsr + 1);                        // this row's B reads are done (same wave: program order)
@@ -472,7 +486,7 @@ int launch_local_bwd_f8(hipStream_t st, const float* x, const float* y, int64_t 
     const int PS = (int)(P * S);
     float* gexp = reinterpret_cast<float*>(ws);
     unsigned char* gpack = reinterpret_cast<unsigned char*>(ws) + (size_t)((PS * 4 + 255) / 256 * 256);
-    hipLaunchKernelGGL(gexp_kernel, dim3(PS), dim3(256), 0, st, grad_raw, C::T * C::T * 20 * 20, gexp);
+    hipLaunchKernelGGL(gexp_kernel, dim3(PS), dim3(1024), 0, st, grad_raw, C::T * C::T * 20 * 20, gexp);
     const int total = PS * 2 * (C::KS * C::MP * 32 + C::NI * 8 * C::MP * 4);
     hipLaunchKernelGGL((pack_g_f8_kernel<20, 3>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, gexp, PS, gpack);
     const size_t lds = (size_t)C::A16B + C::A8B + (size_t)WAVES * (C::B16P + 2 * C::B8P);

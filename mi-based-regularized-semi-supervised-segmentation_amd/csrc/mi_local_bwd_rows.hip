@@ -346,27 +346,43 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_rows_kernel(const flo
                 default: break;
             }
             // voffset: lane-dependent part (column, channel 4q + r of a main tile / validity), soffset: the wave-uniform row offset
-            auto put = [&](float v, unsigned voff, unsigned soff) {
-                if (ACC) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)voff, (int)soff, 0));
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)voff, (int)soff, 0);
-            };
+            // Store (or, for windows that share pixels with windows of earlier launches, add into) the finished row.  The accumulate form
+            // issues ALL its loads before the first store: a load / add / store chain per element serialises on the memory round trip
+            // (the compiler may not move a load above a store to the same buffer) -- 48 round trips per row and wave made the 49-window
+            // launches of BASELINE configs[3] take 6.3 ms instead of 3.
             const unsigned qplane = (unsigned)(4 * q) * (unsigned)plane * 4u;
+            unsigned vo_m[NT], vo_r[RT][NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned vo = (keep && col0 + nt * 16 + l15 < w1w) ? qplane + (unsigned)(nt * 16 + l15) * 4u : OOB;
+                const bool cok = keep && col0 + nt * 16 + l15 < w1w;
+                vo_m[nt] = cok ? qplane + (unsigned)(nt * 16 + l15) * 4u : OOB;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) put(sc * done[nt][r], vo, rowo + (unsigned)r * (unsigned)plane * 4u);
+                for (int t = 0; t < RT; ++t) vo_r[t][nt] = (cok && t * 4 + q == jdone) ? (unsigned)(nt * 16 + l15) * 4u : OOB;
+            }
+            float old_m[NT][4], old_r[RT][NT][4];
+            if (ACC) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        old_m[nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)vo_m[nt], (int)(rowo + (unsigned)r * (unsigned)plane * 4u), 0));
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            old_r[t][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), 0));
+                    }
             }
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {                 // the four remaining channels of that row: lane-row q of remainder tile t is slot 4t + q
-                const bool mine = t * 4 + q == jdone;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned vo = (keep && mine && col0 + nt * 16 + l15 < w1w) ? (unsigned)(nt * 16 + l15) * 4u : OOB;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = sc * done[nt][r] + (ACC ? old_m[nt][r] : 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)vo_m[nt], (int)(rowo + (unsigned)r * (unsigned)plane * 4u), 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) put(sc * rem[t][nt][r], vo, rowo + (unsigned)(16 + r) * (unsigned)plane * 4u);
+                    for (int t = 0; t < RT; ++t) {
+                        const float vr = sc * rem[t][nt][r] + (ACC ? old_r[t][nt][r] : 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), 0);
+                    }
                 }
-            }
             if (hsr < hs_last) {
                 if (NBUF == 1) fetch_row(hsr + 1);         // this row's B reads are done (same wave: program order)
                 commit_row(NBUF == 2 ? buf ^ 1 : 0);
