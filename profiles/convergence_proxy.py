@@ -70,7 +70,7 @@ def run_product(dtype, data, args):
     from semi_seg._utils import IICLossWrapper, ProjectorWrapper
     from semi_seg.epocher import UDAIICEpocher
     dev = "cuda"
-    ops.set_mi_precision("bf16x3" if dtype in ("bfloat16", "float16") else "fp32")
+    ops.set_mi_precision(os.environ.get("MISEG_PROXY_MI", "f16f8") if dtype in ("bfloat16", "float16") else "fp32")   # the bench's arithmetic
     model = UNet(1, 4, compute_dtype=dtype)
     model.load_state_dict(OU.init_state(1, 4, seed=21 + 100 * args.run_seed))
     pw = ProjectorWrapper()
