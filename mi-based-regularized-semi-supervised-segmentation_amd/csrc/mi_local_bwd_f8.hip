@@ -42,8 +42,12 @@
 //     hand between the MFMAs (built and measured, not kept): zero spills, 1.11 ms.  A lone wave issues ~1 instruction per 8
 //     cycles and the filler instructions do NOT disappear behind 16- or 32-cycle MFMAs of these shapes: 180 + 108 MFMAs alone 4 050 +
 //     3 770 cycles per row (ideal 2 880 + 3 456), with the ~400 filler instructions 6 200 + 6 500.
-//   So this kernel is bound by instruction issue and LDS round trips around the MFMAs, not by the matrix pipe (45-50 % busy): the
-//   third of the MFMA cycles the split saves shows up as 11 %.
+//   So this kernel is bound by instruction issue and LDS round trips around the MFMAs, not by the matrix pipe (~52 % busy): the
+//   third of the MFMA cycles the split saves shows up as 11 %.  Where a wave's time goes in the shipped form (s_memtime stamps,
+//   -DMISEG_F8_STAMP=1, cycles per source row and wave): fetch + split + commit 4 900, f16 phase 5 900, fp8 phase 4 900, output
+//   switch + stores 1 700 = 17 400 for 2 x 6 336 cycles of MFMA per SIMD (73 % inside the loop); a wave walks 86-98 source rows for its
+//   80 output rows (2 PAD warm-up rows per unit, one or two units per wave) and the launch ends with its slowest wave.  Raising the
+//   issue priority of the non-MFMA phases (s_setprio) changed nothing.
 #include "mi_local.h"
 
 #ifndef MISEG_F8_D1
@@ -54,6 +58,9 @@
 #endif
 #ifndef MISEG_F8_EDGE1
 #define MISEG_F8_EDGE1 1
+#endif
+#ifndef MISEG_F8_STAMP
+#define MISEG_F8_STAMP 0     // diagnostic build: per-phase s_memtime sums of every wave -> the tail of the workspace (scratch/f8_stamps.py)
 #endif
 #ifndef MISEG_F8_ABL
 #define MISEG_F8_ABL 0       // ablation builds (scratch): 1 = no per-row fetch / commit, 2 = no output stores
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                                                               const int32_t* __restrict__ win,
                                                               const unsigned char* __restrict__ gpack, const float* __restrict__ gexp,
                                                               const float* __restrict__ scale, float* __restrict__ gx,
-                                                              float* __restrict__ gy) {
+                                                              float* __restrict__ gy, unsigned long long* __restrict__ stamps) {
     typedef Q3<K, PAD, NTW> C;
     constexpr int T = C::T, RT = C::RT, NT = C::NT, KS = C::KS, NI = C::NI, MP = C::MP, CS = C::CS, CS8 = C::CS8;
     constexpr int BWB = C::B16P + 2 * C::B8P;            // bytes of one wave's source-row buffer: f16 plane, 8-bit lo plane, 8-bit hi plane
@@ -178,6 +185,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
     // never 0x7F / 0xFF -- cleared once; commit_row rewrites whole pixels (24 bytes) afterwards
     for (int i = lane; i < BWB / 4; i += 64) reinterpret_cast<unsigned*>(Bw)[i] = 0u;
 
+#if MISEG_F8_STAMP
+    unsigned long long st_fetch = 0, st_p1 = 0, st_p2 = 0, st_out = 0, st_t = __builtin_amdgcn_s_memtime(), st_rows = 0;
+#define F8_STAMP(acc_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_t; st_t = now_; }
+#else
+#define F8_STAMP(acc_)
+#endif
     // ---- work = output rows, dealt as in local_bwd_rows_kernel: equal contiguous shares per block, per wave inside one sdp
     int64_t rows_head = 0;
     for (int p = 0; p < g.P; ++p) {
@@ -354,6 +367,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                 const int hj = hsr + PAD - (ph - j) % T;
                 open_row[j] = hj >= r0 && hj < r1;
             }
+            F8_STAMP(st_fetch)
             {
                 // ---- phase 1: hi x hi on the f16 pipe; edge slots (output row outside the unit) skipped behind a wave-uniform branch per tile
                 constexpr int D1 = MISEG_F8_D1, NBQ = MISEG_F8_BQ;
@@ -383,6 +397,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                     }
                 }
             }
+            F8_STAMP(st_p1)
             __builtin_amdgcn_sched_barrier(0);            // phase 2's first fragment loads stay behind phase 1's last MFMAs (they would not fit beside its registers)
             {
                 // ---- phase 2: both cross terms, K-concatenated, on the block-scaled fp8 pipe
@@ -407,6 +422,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                     }
                 }
             }
+            F8_STAMP(st_p2)
             // ---- the slot with tau = T-1 now holds output row h = hsr - PAD
             const int h = hsr - PAD;
             const bool keep = h >= r0;
@@ -458,6 +474,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), 0);
                     }
                 }
+            F8_STAMP(st_out)
+#if MISEG_F8_STAMP
+            ++st_rows;
+#endif
 #if !(MISEG_F8_ABL & 1)
             if (hsr < hs_last) {
                 fetch_row(hsr + 1);                        // this row's B reads are done (same wave: program order)
@@ -467,12 +487,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
         }
       }
     }
+#if MISEG_F8_STAMP
+    if (lane == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * WAVES + wv) * 8;
+        o[0] = st_fetch; o[1] = st_p1; o[2] = st_p2; o[3] = st_out; o[4] = st_rows;
+    }
+#endif
 }
 
 size_t local_bwd_f8_ws_bytes(int64_t K, int64_t pad, int64_t P) {
     if (K != 20 || pad != 3) return 0;
     typedef Q3<20, 3> C;
-    return (size_t)256 + (size_t)((P * 4 + 255) / 256 * 256) + (size_t)P * 2 * (C::A16B + C::A8B);
+    return (size_t)256 + (size_t)((P * 4 + 255) / 256 * 256) + (size_t)P * 2 * (C::A16B + C::A8B) + (MISEG_F8_STAMP ? 256 * 8 * 64 : 0);
 }
 
 bool local_bwd_f8_supported(int64_t K, int64_t pad) { return K == 20 && pad == 3; }
@@ -492,7 +518,8 @@ int launch_local_bwd_f8(hipStream_t st, const float* x, const float* y, int64_t 
     const size_t lds = (size_t)C::A16B + C::A8B + (size_t)WAVES * (C::B16P + 2 * C::B8P);
     auto go = [&](auto kernel) {
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, dim3(g.G), dim3(64 * WAVES), lds, st, x, y, g, win, gpack, gexp, scale, gx, gy);
+        hipLaunchKernelGGL(kernel, dim3(g.G), dim3(64 * WAVES), lds, st, x, y, g, win, gpack, gexp, scale, gx, gy,
+                           reinterpret_cast<unsigned long long*>(gpack + (size_t)PS * 2 * (C::A16B + C::A8B)));
     };
     if (g.accumulate) go(local_bwd_f8_kernel<20, 3, true, 4, WAVES>);
     else go(local_bwd_f8_kernel<20, 3, false, 4, WAVES>);
