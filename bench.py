@@ -395,11 +395,25 @@ def main():
     if distributed and getattr(ep, "_reducer", None) is not None:
         ep._reducer.timing = True
         ep._reducer._wait_events = []
+    # how long the host is BLOCKED per step (the one wait of an iteration: the previous iteration's scalars, _Pending.wait): the loop
+    # time minus this is what the host spends enqueueing a step -- the figure that says whether the host or the GPU limits the rate
+    from semi_seg.epocher import _Pending
+    blocked = [0.0]
+    real_wait = _Pending.wait
+
+    def timed_wait(ticket):
+        tb = time.perf_counter()
+        out = real_wait(ticket)
+        blocked[0] += time.perf_counter() - tb
+        return out
+    _Pending.wait = staticmethod(timed_wait)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
     t_host = time.perf_counter() - t0   # host-side loop time (each step waits for the PREVIOUS step's scalars, so it tracks the GPU)
+    t_blocked = blocked[0]
+    _Pending.wait = staticmethod(real_wait)
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0   # this rank alone: its queue drained, before the barrier that waits for the slowest rank
     barrier()
@@ -408,6 +422,7 @@ def main():
     # what each rank saw (N > 1: so that a scaling curve explains itself): its own step time, how long its host spent enqueueing a
     # step, how long its gradient stream waited for the all-reduces after backward had finished (the EXPOSED collective time)
     mine = {"rank": rank, "ms_per_step": round(1000.0 * dt_own / args.steps, 3), "host_loop_ms_per_step": round(1000.0 * t_host / args.steps, 3),
+            "host_busy_ms_per_step": round(1000.0 * (t_host - t_blocked) / args.steps, 3),
             "allreduce_exposed_ms_per_step": None}
     if distributed and getattr(ep, "_reducer", None) is not None:
         ex = ep._reducer.exposed_ms()

@@ -319,6 +319,32 @@ int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y,
                            int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
                            int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes,
                            int32_t* sync_counter);
+/* BatchNorm backward folded into the convolutions around it (ref: unet.py:14-21, 31-36 -- what autograd runs as
+ * threshold_backward -> native_batch_norm_backward -> convolution_backward becomes two launches per layer):
+ *   bn_relu_bwd_stats : the statistics half of bn_relu_bwd for a layer WITHOUT the fused pool: ggamma, gbeta and
+ *                       bwd_coef = fp32[6][C] (scale | shift | mean | A | P | Q) with which a consumer forms
+ *                       graw = [relu(raw*scale+shift) > 0] * A * gy + P + Q * (raw - mean)
+ *                       (A = gamma*invstd, P = -A*mean(dz), Q = -A*invstd*mean(dz*xhat); P = Q = 0 in eval mode) -- the tensor
+ *                       bn_relu_bwd would have written.  ext_parts != NULL: the per-block sums [ext_nparts][2][C] were already taken
+ *                       by the epilogue of the convolution that wrote gy (conv3x3_dgrad_bn's red_* arguments); raw / gy / ws unused.
+ *   conv3x3_dgrad_bn  : conv3x3_fwd(pack kind 1) over graw formed in the tile loader from (raw, gy, bwd_coef) -- K = the layer's
+ *                       output channels, Cs = channels of the gradient written; gy == NULL: raw_or_graw is a plain graw tensor.
+ *                       pool_out: the output leaves 2x2 sum-pooled (conv3x3_fwd_sumpool).  red_raw != NULL (full-resolution output
+ *                       only): `out` is the activation gradient of ANOTHER BatchNorm layer whose raw output / saved[4][Cs] are
+ *                       red_raw / red_saved; the epilogue writes that layer's per-block backward sums to red_parts
+ *                       [conv3x3_dgrad_red_parts(...)][2][Cs] (0 parts: not available for the shape).
+ *   conv3x3_wgrad_bn  : conv3x3_wgrad with the same loader in place of gout. */
+int miseg_bn_relu_bwd_stats(void* stream, int dt, const void* raw, const void* gy, int64_t N, int64_t H, int64_t W, int64_t C,
+                            const float* gamma, const float* saved, int training, float* bwd_coef, float* ggamma,
+                            float* gbeta, const float* ext_parts, int64_t ext_nparts, void* ws, int64_t ws_bytes);
+int64_t miseg_conv3x3_dgrad_bn_supported(int dt, int64_t K, int64_t N, int64_t H, int64_t W, int64_t Cs, int pool_out);
+int64_t miseg_conv3x3_dgrad_red_parts(int dt, int64_t K, int64_t N, int64_t H, int64_t W, int64_t Cs);
+int miseg_conv3x3_dgrad_bn(void* stream, int dt, const void* raw_or_graw, const void* gy, const float* bwd_coef, int64_t K,
+                           int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cs, void* out, int pool_out,
+                           const void* red_raw, const float* red_saved, float* red_parts);
+int miseg_conv3x3_wgrad_bn(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
+                           int ups1, int64_t N, int64_t H, int64_t W, const void* raw, const void* gy,
+                           const float* bwd_coef, int64_t Cout, float* gw_oihw, void* ws, int64_t ws_bytes);
 /* backward of nearest x2 upsample: out[n,h,w,c] = sum of the 2x2 block of in (NHWC dt). */
 int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out,
                      int accumulate);

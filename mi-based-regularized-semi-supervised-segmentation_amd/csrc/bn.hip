@@ -7,29 +7,6 @@
 
 namespace miseg {
 
-template <typename T> struct VT;
-template <> struct VT<float> {
-    static constexpr int V = 4;
-    typedef float4 Raw;
-    static __device__ __forceinline__ void unpack(const Raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
-    static __device__ __forceinline__ Raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
-};
-template <> struct VT<bf16> {
-    static constexpr int V = 8;
-    typedef uint4 Raw;
-    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
-        const unsigned u[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32((unsigned short)(u[i] & 0xffffu)); f[2 * i + 1] = bf16_bits_to_f32((unsigned short)(u[i] >> 16)); }
-    }
-    static __device__ __forceinline__ Raw pack(const float* f) {
-        unsigned u[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16);
-        return make_uint4(u[0], u[1], u[2], u[3]);
-    }
-};
-
 // ---- statistics -> coefficients.  saved = [mean | invstd | scale | shift] (4*C floats)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -206,7 +183,21 @@ struct BnBwdFinish {
     unsigned int* counter;           // null: bn_bwd_finalize_kernel is launched separately
     const float* gamma; float* coeffs; float* ggamma; float* gbeta;
     float count; int training;
+    float* bwd_coef;                 // null or [6][C] (common.h, BnLoad): the coefficients of the loader-fused backward
 };
+// what one channel's sums become: coeffs[3][C] for bn_bwd_apply_kernel and / or bwd_coef[6][C] for the fused loaders
+__device__ __forceinline__ void bn_bwd_coeffs(int c, int C, float s1, float s2, float count, int training, const float* __restrict__ gamma,
+                                              const float* __restrict__ saved, float* __restrict__ coeffs, float* __restrict__ bwd_coef,
+                                              float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    gbeta[c] = s1;
+    ggamma[c] = s2;
+    const float a = gamma[c] * saved[C + c], b = training ? s1 / count : 0.f, cc = training ? s2 / count : 0.f;
+    if (coeffs) { coeffs[c] = a; coeffs[C + c] = b; coeffs[2 * C + c] = cc; }
+    if (bwd_coef) {
+        bwd_coef[c] = saved[2 * C + c]; bwd_coef[C + c] = saved[3 * C + c]; bwd_coef[2 * C + c] = saved[c];
+        bwd_coef[3 * C + c] = a; bwd_coef[4 * C + c] = -(a * b); bwd_coef[5 * C + c] = -(a * saved[C + c] * cc);
+    }
+}
 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ raw, const T* __restrict__ gy,
@@ -258,14 +249,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
     }
     if (fin.counter && last_block_arrives(fin.counter, gridDim.x)) {      // the body of bn_bwd_finalize_kernel, by the last block
         const float* sums = block_column_sums(parts, (int)gridDim.x, 2 * C, sacc);     // sacc: 256 * 2V >= 1024 + 2C floats (host-checked)
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const float s1 = sums[c], s2 = sums[C + c];
-            fin.gbeta[c] = s1;
-            fin.ggamma[c] = s2;
-            fin.coeffs[c] = fin.gamma[c] * saved[C + c];
-            fin.coeffs[C + c] = fin.training ? s1 / fin.count : 0.f;
-            fin.coeffs[2 * C + c] = fin.training ? s2 / fin.count : 0.f;
-        }
+        for (int c = threadIdx.x; c < C; c += 256)
+            bn_bwd_coeffs(c, C, sums[c], sums[C + c], fin.count, fin.training, fin.gamma, saved, fin.coeffs, fin.bwd_coef, fin.ggamma, fin.gbeta);
         last_block_done(fin.counter);
     }
 }
@@ -274,7 +259,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                                               const float* __restrict__ gamma, const float* __restrict__ saved,
                                                               int training, float* __restrict__ coeffs, float* __restrict__ ggamma,
-                                                              float* __restrict__ gbeta) {
+                                                              float* __restrict__ gbeta, float* __restrict__ bwd_coef) {
     __shared__ float red[17];
     const int c = blockIdx.x;
     float s1 = 0.f, s2 = 0.f;
@@ -284,13 +269,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
-    if (threadIdx.x == 0) {
-        gbeta[c] = s1;
-        ggamma[c] = s2;
-        coeffs[c] = gamma[c] * saved[C + c];
-        coeffs[C + c] = training ? s1 / count : 0.f;
-        coeffs[2 * C + c] = training ? s2 / count : 0.f;
-    }
+    if (threadIdx.x == 0) bn_bwd_coeffs(c, C, s1, s2, count, training, gamma, saved, coeffs, bwd_coef, ggamma, gbeta);
 }
 
 // graw = a*(dz - b - xhat*c), dz recomputed from (raw, gy[, gpool])
@@ -445,13 +424,11 @@ extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_
     return ((int64_t)red_blocks(N * H * W, 1) * 2 * C + 3 * C) * 4;
 }
 
-extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
-                                      int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
-                                      float* ggamma, float* gbeta, void* ws, int64_t ws_bytes, int32_t* sync_counter) {
-    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_sync, stream, MISEG_BF16, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws,
-                          ws_bytes, sync_counter);
-    (void)y;   // kept in the signature; the ReLU mask and pool routing are recomputed from raw (see bn_dz_foreach)
-    MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && graw && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
+// reduce (+ finalize) (+ apply): graw == null stops after the statistics, which then leave as bwd_coef for the fused loaders of conv.hip
+static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* gy, const void* gpool, int64_t N, int64_t H, int64_t W, int64_t C,
+                            const float* gamma, const float* saved, int training, void* graw, float* ggamma, float* gbeta, void* ws,
+                            int64_t ws_bytes, int32_t* sync_counter, float* bwd_coef) {
+    MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && (graw || bwd_coef) && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     const int CV = (int)(C / V);
     MISEG_REQUIRE(C % V == 0 && 256 % CV == 0, "bn_relu_bwd: C/%d must divide 256", V);
@@ -467,7 +444,7 @@ extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, con
     // one block (common.h, "last block finishes"); its scratch is the reduce's own LDS, widened to 1024 + 2C floats if need be
     const bool finish = sync_counter && C % 4 == 0 && C <= 256 && (int64_t)nb * 2 * C <= kFinishFloats;
     const size_t lb = std::max<size_t>((size_t)256 * 2 * V * 4, finish ? (size_t)(1024 + 2 * C) * 4 : 0);
-    BnBwdFinish fin{finish ? reinterpret_cast<unsigned int*>(sync_counter) : nullptr, gamma, coeffs, ggamma, gbeta, (float)npix, training};
+    BnBwdFinish fin{finish ? reinterpret_cast<unsigned int*>(sync_counter) : nullptr, gamma, coeffs, ggamma, gbeta, (float)npix, training, bwd_coef};
 #define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts, fin)
     if (dt == MISEG_F32) { if (gpool) RED(float, true); else RED(float, false); }
     else if (dt == MISEG_BF16) { if (gpool) RED(bf16, true); else RED(bf16, false); }
@@ -475,9 +452,10 @@ extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, con
 #undef RED
     MISEG_LAUNCH_CHECK("bn_relu_bwd_reduce_kernel");
     if (!finish) {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta, bwd_coef);
         MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     }
+    if (!graw) return MISEG_OK;
     // elementwise pass: many more blocks than the reduce (no partials to bound), same thread -> channel-vector mapping
     const int na = ew_blocks((gpool ? npix / 4 : npix) * CV);
 #define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw)
@@ -486,6 +464,32 @@ extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, con
 #undef APP
     MISEG_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return MISEG_OK;
+}
+
+extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
+                                      int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
+                                      float* ggamma, float* gbeta, void* ws, int64_t ws_bytes, int32_t* sync_counter) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_sync, stream, MISEG_BF16, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws,
+                          ws_bytes, sync_counter);
+    (void)y;   // kept in the signature; the ReLU mask and pool routing are recomputed from raw (see bn_dz_foreach)
+    MISEG_REQUIRE(graw, "bn_relu_bwd: null pointer");
+    return bn_relu_bwd_impl(stream, dt, raw, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, sync_counter, nullptr);
+}
+
+extern "C" int miseg_bn_relu_bwd_stats(void* stream, int dt, const void* raw, const void* gy, int64_t N, int64_t H, int64_t W, int64_t C,
+                                       const float* gamma, const float* saved, int training, float* bwd_coef, float* ggamma, float* gbeta,
+                                       const float* ext_parts, int64_t ext_nparts, void* ws, int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_stats, stream, MISEG_BF16, raw, gy, N, H, W, C, gamma, saved, training, bwd_coef, ggamma, gbeta, ext_parts,
+                          ext_nparts, ws, ws_bytes);
+    MISEG_REQUIRE(bwd_coef, "bn_relu_bwd_stats: null pointer");
+    if (ext_parts) {      // the sums were taken by the epilogue of the convolution that wrote gy (miseg_conv3x3_dgrad_bn)
+        MISEG_REQUIRE(gamma && saved && ggamma && gbeta && ext_nparts > 0 && C > 0, "bn_relu_bwd_stats: bad args");
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), ext_parts, (int)ext_nparts, (int)C,
+                           (float)(N * H * W), gamma, saved, training, (float*)nullptr, ggamma, gbeta, bwd_coef);
+        MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+        return MISEG_OK;
+    }
+    return bn_relu_bwd_impl(stream, dt, raw, gy, nullptr, N, H, W, C, gamma, saved, training, nullptr, ggamma, gbeta, ws, ws_bytes, nullptr, bwd_coef);
 }
 
 extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,

@@ -103,6 +103,73 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
 }
 #endif
 
+// ---- 16-byte vectors of the NHWC activation tensors: V elements of T <-> V floats
+template <typename T> struct VT;
+template <> struct VT<float> {
+    static constexpr int V = 4;
+    typedef float4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+    static __device__ __forceinline__ Raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct VT<bf16> {
+    static constexpr int V = 8;
+    typedef uint4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+        const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32((unsigned short)(u[i] & 0xffffu)); f[2 * i + 1] = bf16_bits_to_f32((unsigned short)(u[i] >> 16)); }
+    }
+    static __device__ __forceinline__ Raw pack(const float* f) {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+        return make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+
+// y = T(relu(x)) is > 0 exactly when x exceeds the largest fp32 that T rounds to zero: the ReLU mask of the BatchNorm backward is
+// recomputed from the raw convolution output (bn.hip, conv.hip) and must agree with the activation as it was STORED.
+template <typename T> __device__ __forceinline__ float relu_keep_threshold();
+template <> __device__ __forceinline__ float relu_keep_threshold<float>() { return 0.f; }
+#ifdef MISEG_F16_BUILD
+template <> __device__ __forceinline__ float relu_keep_threshold<bf16>() { return 0x1p-25f; }    // half: ties-to-even at half the smallest subnormal
+#else
+template <> __device__ __forceinline__ float relu_keep_threshold<bf16>() { return 0x1p-134f; }
+#endif
+
+// BatchNorm backward folded into the convolutions that consume it (conv.hip; coefficients written by bn_bwd_finalize_kernel):
+//   graw = m * A * gy + P + Q * (raw - mean),   m = [T(relu(raw * scale + shift)) > 0]
+// with A = gamma * invstd, P = -A * mean(dz), Q = -A * invstd * mean(dz * xhat) (training; P = Q = 0 in eval mode): the tensor
+// bn_bwd_apply_kernel would have written, formed in the loader of the data- / weight-gradient kernel instead.
+constexpr int kBwdCoefRows = 6;      // coef[6][C]: scale | shift | mean | A | P | Q
+struct BnLoad {
+    const void* gy;                  // gradient of the layer's activation (NHWC T), same shape as the raw tensor; null: plain source
+    const float* coef;
+};
+// ... and the statistics pass of the PRODUCER of the tensor whose gradient a data-gradient launch writes, taken in its epilogue:
+// parts[block][2][C] = per-block sum(dz), sum(dz * xhat) with dz = [y > 0] * (the gradient as stored), for bn_bwd_finalize_kernel.
+struct BnRed {
+    const void* raw;                 // the producer's raw convolution output, shape of this launch's output; null: off
+    const float* saved;              // its saved[4][C]: mean | invstd | scale | shift
+    float* parts;
+};
+template <typename T>
+__device__ __forceinline__ typename VT<T>::Raw bn_graw_vec(const typename VT<T>::Raw& rraw, const typename VT<T>::Raw& rgy, const float* sc,
+                                                           const float* sh, const float* mu, const float* ca, const float* cp, const float* cq) {
+    constexpr int V = VT<T>::V;
+    float fr[V], fg[V];
+    VT<T>::unpack(rraw, fr);
+    VT<T>::unpack(rgy, fg);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float yv = fr[i] * sc[i] + sh[i];
+        const float lin = cp[i] + cq[i] * (fr[i] - mu[i]);
+        fg[i] = yv > relu_keep_threshold<T>() ? ca[i] * fg[i] + lin : lin;
+    }
+    return VT<T>::pack(fg);
+}
+
 // ---- wave64 / block reductions --------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -56,9 +56,13 @@ __device__ __forceinline__ void zero_vec(T* dst) {
 
 // COT: output channels per block; TW: tile width (32 or 16).  grid = (N*tilesR*tilesC, ceil(Cout/COT)).
 // POOL: as in conv3x3_stream_kernel below -- the output leaves 2x2 sum-pooled (H, W even; no statistics).
-template <typename T, int COT, int TW, int THT, bool POOL = false>
+// BNL: the (single, full-resolution) source is a BatchNorm layer's raw output and bl.gy the gradient of its activation -- the loader
+// forms graw (common.h, bn_graw_vec); out-of-image halo pixels stay zero.  RED: the epilogue also takes the BatchNorm-backward sums of
+// the layer that produced this launch's output tensor (BnRed; non-pooled output, Cout % 4 == 0, no forward statistics).
+template <typename T, int COT, int TW, int THT, bool POOL = false, bool BNL = false, bool RED = false>
 __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
-                                                        T* __restrict__ out, float* __restrict__ stats, BnFinish fin) {
+                                                        T* __restrict__ out, float* __restrict__ stats, BnFinish fin, BnLoad bl, BnRed br) {
+    static_assert(!(RED && POOL), "the epilogue reduce exists for full-resolution outputs");
     typedef Mma<T> MM;
     constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, RW = THT / 4, MTW = RW * MTR;   // RW rows of the tile per wave
     constexpr int KP = MM::KP;                              // LDS stride of one pixel / one weight row (elements)
@@ -82,8 +86,23 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
     // One 32-channel chunk of the haloed input tile and of the weights is in flight in registers while the previous
     // chunk is on the matrix cores (the block is alone on its CU: 1 wave per SIMD, so nothing else hides the latency).
     uint4 pin[NIS], pwt[NWS];
+    uint4 pgy[BNL ? NIS : 1];                    // BNL: the activation gradient beside the raw output, the slot's coefficients,
+    float cfr[BNL ? kBwdCoefRows * VEC : 1];     // and which slots lie inside the image (the others stay zero, not P - Q * mean)
+    unsigned okm = 0;
+    static_assert(NIS <= 32 && kCT % (CK / VEC) == 0, "slot mask / per-thread channel vector");
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    auto fetch = [&](int c0) {
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+        if (BNL) {
+            okm = 0;
+            const int c = c0 + (tid % (CK / VEC)) * VEC;         // the same channel vector in every slot of this thread
+#pragma unroll
+            for (int r = 0; r < kBwdCoefRows; ++r)
+#pragma unroll
+                for (int i = 0; i < VEC; i += 4) {
+                    const float4 q = c < Cin ? *reinterpret_cast<const float4*>(bl.coef + (size_t)r * Cin + c + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    cfr[r * VEC + i] = q.x; cfr[r * VEC + i + 1] = q.y; cfr[r * VEC + i + 2] = q.z; cfr[r * VEC + i + 3] = q.w;
+                }
+        }
 #pragma unroll
         for (int j = 0; j < NIS; ++j) {
             const int idx = tid + kCT * j;
@@ -92,7 +111,12 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
             uint4 val = zero4;
             if (idx < IH * IW * (CK / VEC) && h >= 0 && h < H && w >= 0 && w < W && c < Cin) {
                 const T* sp;
-                if (c < src.C0) {
+                if (BNL) {
+                    const size_t o = (((size_t)n * H + h) * W + w) * src.C0 + c;
+                    sp = reinterpret_cast<const T*>(src.p0) + o;
+                    pgy[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(bl.gy) + o);
+                    okm |= 1u << j;
+                } else if (c < src.C0) {
                     const int hs = H >> src.ups0, wsz = W >> src.ups0;
                     sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
                 } else {
@@ -118,12 +142,23 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
     const T* Ib = Is + ((wv * RW) * IW + l15) * KP;
     const T* Wb = Ws + l15 * KP;
     fetch(0);
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
+    auto chunk = [&](int c0) __attribute__((always_inline)) {
         __syncthreads();                       // previous chunk's MFMAs are done with Is / Ws
 #pragma unroll
         for (int j = 0; j < NIS; ++j) {
             const int idx = tid + kCT * j;
-            if (idx < IH * IW * (CK / VEC)) *reinterpret_cast<uint4*>(Is + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pin[j];
+            if (idx < IH * IW * (CK / VEC)) {
+                uint4 val = pin[j];
+                if (BNL) {
+                    typedef typename VT<T>::Raw Raw;
+                    if ((okm >> j) & 1u) {
+                        const Raw g = bn_graw_vec<T>(*reinterpret_cast<const Raw*>(&pin[j]), *reinterpret_cast<const Raw*>(&pgy[j]), cfr, cfr + VEC,
+                                                     cfr + 2 * VEC, cfr + 3 * VEC, cfr + 4 * VEC, cfr + 5 * VEC);
+                        val = *reinterpret_cast<const uint4*>(&g);
+                    } else val = zero4;
+                }
+                *reinterpret_cast<uint4*>(Is + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = val;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NWS; ++j) {
@@ -145,6 +180,45 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
                 for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);   // D^T: rows = channels, cols = pixels
             }
         }
+    };
+    // RED: the producer's raw output at this block's output positions (a lane's 4 channels of a pixel per (m, t)) and its coefficients
+    // are requested before the LAST chunk goes to the matrix cores, so that they have arrived when the epilogue wants them
+    struct RedQuad { float v[4]; };
+    RedQuad rp[RED ? MTW : 1][RED ? NT : 1];
+    float rsc[RED ? NT : 1][4], rsh[RED ? NT : 1][4], rmu[RED ? NT : 1][4];
+    if (RED) {
+        int c0 = 0;
+        for (; c0 + CK < Cin; c0 += CK) chunk(c0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co = co0 + t * 16 + kq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = co + r < Cout;
+                rmu[t][r] = in ? br.saved[co + r] : 0.f;
+                rsc[t][r] = in ? br.saved[2 * Cout + co + r] : 0.f;
+                rsh[t][r] = in ? br.saved[3 * Cout + co + r] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+            const T* rq = reinterpret_cast<const T*>(br.raw) + (((size_t)n * H + h) * W + w) * Cout;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co0 + t * 16 + kq * 4;
+                T q[4] = {from_f32<T>(0.f), from_f32<T>(0.f), from_f32<T>(0.f), from_f32<T>(0.f)};
+                if (h < H && w < W && co + 3 < Cout) {
+                    if (sizeof(T) == 2) *reinterpret_cast<uint2*>(q) = *reinterpret_cast<const uint2*>(rq + co);
+                    else *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(rq + co);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rp[m][t].v[r] = to_f32(q[r]);
+            }
+        }
+        chunk(c0);
+    } else {
+        for (int c0 = 0; c0 < Cin; c0 += CK) chunk(c0);
     }
     // ---- epilogue: D^T[row = channel t*16 + kq*4 + r][col = pixel l15]: a lane owns 4 consecutive channels of one pixel, so
     // the 16 lanes x 4 kq of a wave store whole NHWC pixel vectors (8-byte pieces, contiguous across kq)
@@ -199,8 +273,15 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[m][t][r];
                     pk[r] = from_f32<T>(v);
-                    s1[t][r] += v;
-                    s2[t][r] += v * v;
+                    if (RED) {      // dz = [y > 0] * (the gradient as the producer's backward will read it); sum dz, sum dz * (raw - mean)
+                        const float x = rp[m][t].v[r];
+                        const float dz = x * rsc[t][r] + rsh[t][r] > relu_keep_threshold<T>() ? to_f32(pk[r]) : 0.f;
+                        s1[t][r] += dz;
+                        s2[t][r] += dz * (x - rmu[t][r]);
+                    } else {
+                        s1[t][r] += v;
+                        s2[t][r] += v * v;
+                    }
                 }
                 if (sizeof(T) == 2) *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
                 else *reinterpret_cast<uint4*>(op + co) = *reinterpret_cast<const uint4*>(pk);
@@ -216,6 +297,7 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
             }
         }
     }
+    if (RED) stats = br.parts;
     if (stats) {
         __shared__ float sred[4][2][COT];
 #pragma unroll
@@ -234,10 +316,11 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
         if (tid < COT && co0 + tid < Cout) {
             float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
             float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+            if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
             store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
             store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
         }
-        if (fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {   // the tile memory is dead: scratch for the sums
+        if (!RED && fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {   // the tile memory is dead: scratch for the sums
             bn_finish_block(stats, (int)gridDim.x, Cout, fin, reinterpret_cast<float*>(smem));
             last_block_done(fin.counter);
         }
@@ -257,27 +340,50 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 // POOL: the output leaves 2x2 sum-pooled ([N, H/2, W/2, Cout]; H, W even) -- the backward of a convolution whose input was read
 // through a nearest x2 upsample: its data gradient at full resolution (4x the bytes of what is wanted) is never written; the four
 // fp32 accumulators of a 2x2 block are added (two registers of the lane, then its neighbour's sum) and rounded once.
-template <int COT, int TW, int NVEC, bool DUAL, bool POOL = false>
+// BNL / RED: as in conv3x3_kernel.  The loader keeps the raw output and the activation gradient of the next tile in registers and
+// forms graw when the tile is committed to LDS (coefficients staged in LDS once per block); the epilogue reduce reads the producer's
+// raw output at the tile's output positions after the tile has left the matrix cores and adds it up one iteration late, from the
+// packed gradient registers, just before they are stored.
+template <int COT, int TW, int NVEC, bool DUAL, bool POOL = false, bool BNL = false, bool RED = false, int RW = 4>
 __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ wpk, int Cout,
-                                                               bf16* __restrict__ out, float* __restrict__ stats, int ntiles, BnFinish fin) {
+                                                               bf16* __restrict__ out, float* __restrict__ stats, int ntiles, BnFinish fin,
+                                                               BnLoad bl, BnRed br) {
     typedef bf16 T;
     typedef Mma<T> MM;
-    constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = 4 * MTR;
+    static_assert(!BNL || (!DUAL && (NVEC == 1 || NVEC == 2 || NVEC == 4)), "BN loader: one source, a thread keeps one channel vector");
+    static_assert(!(RED && POOL), "the epilogue reduce exists for full-resolution outputs");
+    // RW rows of a tile per wave: 4 (16-row tiles), or 2 for the fused forms with 32 output or 32 input channels, whose
+    // accumulators, packed outputs and second operand stream do not fit 256 registers at 4
+    constexpr int THS = 4 * RW;
+    static_assert(RW == 2 || RW == 4, "rows per wave");
+    constexpr int CKP = MM::CKP, VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, MTW = RW * MTR;
     // pixel stride of the input tile: 48 elements (24 dwords) makes the 16-lane groups of ds_read_b128 conflict-free
     // (40 is 2-way); taken where the larger tile still leaves two blocks per CU
     constexpr int IKP = COT == 16 ? 48 : CKP;
-    constexpr int IW = TW + 2, IH = TH + 2, NPIX = IH * IW;
+    constexpr int IW = TW + 2, IH = THS + 2, NPIX = IH * IW;
     constexpr int NPF = DUAL ? NVEC * ((NPIX + kCT - 1) / kCT) : (NPIX * NVEC + kCT - 1) / kCT;
     constexpr unsigned OOB = 0xFFFFFF00u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][IKP]
     T* Ws = Is + IH * IW * IKP;                            // [9][COT][CKP]
+    float* Cf = reinterpret_cast<float*>(Ws + 9 * COT * CKP);   // BNL: [6][CK] loader coefficients; RED: + [3][COT] mean | scale | shift
+    float* Rf = Cf + (BNL ? kBwdCoefRows * CK : 0);
     const int Cin = src.C0 + src.C1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int tilesC = (W + TW - 1) / TW, tilesR = (H + TH - 1) / TH;
+    const int tilesC = (W + TW - 1) / TW, tilesR = (H + THS - 1) / THS;
     const int co0 = blockIdx.y * COT;
     const int G = gridDim.x;
     const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (BNL)
+        for (int idx = tid; idx < kBwdCoefRows * CK; idx += kCT) {
+            const int r = idx / CK, c = idx % CK;
+            Cf[idx] = c < Cin ? bl.coef[(size_t)r * Cin + c] : 0.f;
+        }
+    if (RED)
+        for (int idx = tid; idx < 3 * COT; idx += kCT) {
+            const int r = idx / COT, c = co0 + idx % COT;
+            Rf[idx] = c < Cout ? br.saved[(size_t)(r == 0 ? 0 : r + 1) * Cout + c] : 0.f;
+        }
 
     // channels [Cin, CK) of the tile stay zero for the whole kernel; the weight chunk is loaded once
     for (int idx = tid; idx < NPIX * (CK / VEC); idx += kCT) {
@@ -295,8 +401,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
     // ---- tile-invariant slot tables: rel = byte offset from the tile base (pixel (h0-1, w0-1) of the source, after its x2
     // upsampling shift), yx = iy | ix << 8 (0xFFFF for an unused slot), ldso = element offset into Is
     const int hs0 = H >> src.ups0, ws0 = W >> src.ups0, hs1 = H >> src.ups1, ws1 = W >> src.ups1;
-    unsigned rel[NPF], yx[NPF];
-    unsigned short ldso[NPF];
+    unsigned rel[NPF], yx[NPF];          // yx also carries ldso in its upper half (one register per slot instead of two)
 #pragma unroll
     for (int j = 0; j < NPF; ++j) {
         int v, px;
@@ -308,14 +413,16 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         const int ups = from1 ? src.ups1 : src.ups0, wsz = from1 ? ws1 : ws0, Cs = from1 ? src.C1 : src.C0, cs = from1 ? c - src.C0 : c;
         const int ry = ((iy - 1) >> ups) + 1, rx = ((ix - 1) >> ups) + 1;     // >= 0
         rel[j] = (unsigned)(((ry * wsz + rx) * Cs + cs) * 2);
-        yx[j] = used ? (unsigned)(iy | (ix << 8)) : 0xFFFFu;
-        ldso[j] = (unsigned short)(used ? px * IKP + v * VEC : 0);
+        yx[j] = (used ? (unsigned)(iy | (ix << 8)) : 0xFFFFu) | ((unsigned)(used ? px * IKP + v * VEC : 0) << 16);
+        static_assert(NPIX * IKP < 65536, "ldso must fit 16 bits");
     }
 
+    if (BNL || RED) __syncthreads();                       // Cf / Rf are read before the loop's first barrier
     u32x4v pf[NPF];
-    auto fetch = [&](int tile) {
+    u32x4v pg[BNL ? NPF : 1];
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
-        const int h0 = tr * TH, w0 = tc * TW;
+        const int h0 = tr * THS, w0 = tc * TW;
         const int ylo = h0 == 0 ? 1 : 0, yhi = min(IH, H - h0 + 1), xlo = w0 == 0 ? 1 : 0, xhi = min(IW, W - w0 + 1);
         const long long b0 = ((((long long)n * hs0 + (h0 >> src.ups0) - 1) * ws0 + (w0 >> src.ups0) - 1) * src.C0) * 2;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)src.p0 + b0), 0, 0x7FFFFFFF, 0x00020000);
@@ -324,13 +431,55 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             const long long b1 = ((((long long)n * hs1 + (h0 >> src.ups1) - 1) * ws1 + (w0 >> src.ups1) - 1) * src.C1) * 2;
             r1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)src.p1 + b1), 0, 0x7FFFFFFF, 0x00020000);
         }
+        if (BNL) r1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)bl.gy + b0), 0, 0x7FFFFFFF, 0x00020000);   // same shape as the source
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
-            const int iy = yx[j] & 0xFF, ix = yx[j] >> 8;
+            const int iy = yx[j] & 0xFF, ix = (yx[j] >> 8) & 0xFF;
             const bool ok = iy >= ylo && iy < yhi && ix >= xlo && ix < xhi;     // an unused slot has ix = 255
             const unsigned off = ok ? rel[j] : OOB;
             if (DUAL && (j % NVEC) * VEC >= src.C0) pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, (int)off, 0, 0);
             else pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, (int)off, 0, 0);
+            if (BNL) pg[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, (int)off, 0, 0);
+        }
+    };
+    // BNL: graw of the tile's slots (zero outside the image) from (pf, pg) and this thread's channel vector of coefficients
+    auto to_graw = [&](int tile) __attribute__((always_inline)) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR;
+        const int h0 = tr * THS, w0 = tc * TW;
+        const int ylo = h0 == 0 ? 1 : 0, yhi = min(IH, H - h0 + 1), xlo = w0 == 0 ? 1 : 0, xhi = min(IW, W - w0 + 1);
+        // two passes of four channels: 24 coefficient registers live instead of 48 (read from LDS here, every tile -- held across
+        // the MFMA phase they would spill); the result replaces the raw output's half of pf in place
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            asm volatile("" ::: "memory");
+            float4 cf[kBwdCoefRows];
+#pragma unroll
+            for (int r = 0; r < kBwdCoefRows; ++r) cf[r] = *reinterpret_cast<const float4*>(Cf + r * CK + (tid % NVEC) * VEC + 4 * hf);
+            const float sc[4] = {cf[0].x, cf[0].y, cf[0].z, cf[0].w}, sh[4] = {cf[1].x, cf[1].y, cf[1].z, cf[1].w},
+                        mu[4] = {cf[2].x, cf[2].y, cf[2].z, cf[2].w}, ca[4] = {cf[3].x, cf[3].y, cf[3].z, cf[3].w},
+                        cp[4] = {cf[4].x, cf[4].y, cf[4].z, cf[4].w}, cq[4] = {cf[5].x, cf[5].y, cf[5].z, cf[5].w};
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int iy = yx[j] & 0xFF, ix = (yx[j] >> 8) & 0xFF;
+                const bool ok = iy >= ylo && iy < yhi && ix >= xlo && ix < xhi;
+                unsigned o2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned ur = pf[j][2 * hf + i], ug = pg[j][2 * hf + i];
+                    float res[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float fr = bf16_bits_to_f32((unsigned short)(e ? ur >> 16 : ur & 0xffffu));
+                        const float fg = bf16_bits_to_f32((unsigned short)(e ? ug >> 16 : ug & 0xffffu));
+                        const int c = 2 * i + e;
+                        const float lin = cp[c] + cq[c] * (fr - mu[c]);
+                        res[e] = fr * sc[c] + sh[c] > relu_keep_threshold<T>() ? ca[c] * fg + lin : lin;
+                    }
+                    o2[i] = (unsigned)f32_to_bf16_bits(res[0]) | ((unsigned)f32_to_bf16_bits(res[1]) << 16);
+                }
+                pf[j][2 * hf] = ok ? o2[0] : 0u;
+                pf[j][2 * hf + 1] = ok ? o2[1] : 0u;
+            }
         }
     };
 
@@ -344,15 +493,57 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
     int ptile = -1;
-    auto store_prev = [&]() {
+    uint2 rp[RED ? MTW : 1][RED ? NT : 1];       // RED: the producer's raw output at the previous tile's output positions
+    auto load_red = [&](int tile) __attribute__((always_inline)) {
+        const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
+        const int h0 = tr * THS, w0 = tc * TW;
+        const T* rb = reinterpret_cast<const T*>(br.raw) + (((size_t)n * H + h0 + wv * RW) * W + w0 + l15) * Cout + co0 + kq * 4;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint2 q = make_uint2(0u, 0u);
+                if (h < H && w < W && co0 + t * 16 + kq * 4 + 4 <= Cout)
+                    q = *reinterpret_cast<const uint2*>(rb + ((size_t)(m / MTR) * W + (m % MTR) * 16) * Cout + t * 16);
+                rp[m][t] = q;
+            }
+        }
+    };
+    auto store_prev = [&]() __attribute__((always_inline)) {
         const int tc = ptile % tilesC, tr = (ptile / tilesC) % tilesR, n = ptile / (tilesC * tilesR);
-        const int h0 = tr * TH, w0 = tc * TW;
-        const bool full = h0 + TH <= H && w0 + TW <= W && co0 + COT <= Cout;
+        const int h0 = tr * THS, w0 = tc * TW;
+        const bool full = h0 + THS <= H && w0 + TW <= W && co0 + COT <= Cout;
+        if (RED) {      // sums of dz = [y > 0] * (gradient as stored) and dz * (raw - mean) over the previous tile's valid outputs
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 mu = *reinterpret_cast<const float4*>(Rf + t * 16 + kq * 4);
+                const float4 sc = *reinterpret_cast<const float4*>(Rf + COT + t * 16 + kq * 4);
+                const float4 sh = *reinterpret_cast<const float4*>(Rf + 2 * COT + t * 16 + kq * 4);
+                const float mua[4] = {mu.x, mu.y, mu.z, mu.w}, sca[4] = {sc.x, sc.y, sc.z, sc.w}, sha[4] = {sh.x, sh.y, sh.z, sh.w};
+                const bool cok = co0 + t * 16 + kq * 4 + 4 <= Cout;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+                    const bool ok = full || (h < H && w < W && cok);
+                    const T* ge = reinterpret_cast<const T*>(&pk[m][t]);
+                    const T* xe = reinterpret_cast<const T*>(&rp[m][t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = to_f32(xe[r]);
+                        const float dz = (ok && x * sca[r] + sha[r] > relu_keep_threshold<T>()) ? to_f32(ge[r]) : 0.f;
+                        s1[t][r] += dz;
+                        s2[t][r] += dz * (x - mua[r]);
+                    }
+                }
+            }
+        }
         if (POOL) {     // even lanes hold the sums of their 2x2 block: pooled pixel (h0/2 + 2 wv + pr, w0/2 + 8 mc + l15/2)
             const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
             for (int mp = 0; mp < MPK; ++mp) {
-                const int hp = (h0 >> 1) + wv * 2 + mp / MTR, wp = (w0 >> 1) + (mp % MTR) * 8 + (l15 >> 1);
+                const int hp = (h0 >> 1) + wv * (RW / 2) + mp / MTR, wp = (w0 >> 1) + (mp % MTR) * 8 + (l15 >> 1);
                 if ((l15 & 1) || hp >= Hp || wp >= Wp) continue;
                 T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout + co0 + kq * 4;
 #pragma unroll
@@ -373,7 +564,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             }
             return;
         }
-        T* ob = out + (((size_t)n * H + h0 + wv * 4) * W + w0 + l15) * Cout + co0 + kq * 4;
+        T* ob = out + (((size_t)n * H + h0 + wv * RW) * W + w0 + l15) * Cout + co0 + kq * 4;
         if (full) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
@@ -383,7 +574,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         } else {
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+                const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
                 if (h < H && w < W) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -399,11 +590,12 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
     if (lb < ntiles) fetch(lb);
     for (int tile = lb; tile < ntiles; tile += G) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR;
-        const int h0 = tr * TH, w0 = tc * TW;
+        const int h0 = tr * THS, w0 = tc * TW;
+        if (BNL) to_graw(tile);                // in registers, before the barrier: overlaps the other waves' last MFMAs
         __syncthreads();                       // previous tile's MFMAs are done with Is
 #pragma unroll
         for (int j = 0; j < NPF; ++j)
-            if ((yx[j] & 0xFFFFu) != 0xFFFFu) *reinterpret_cast<u32x4v*>(Is + ldso[j]) = pf[j];
+            if ((yx[j] & 0xFFFFu) != 0xFFFFu) *reinterpret_cast<u32x4v*>(Is + (yx[j] >> 16)) = pf[j];
         __syncthreads();
         if (ptile >= 0) store_prev();
         if (tile + G < ntiles) fetch(tile + G);
@@ -413,7 +605,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const T* Ib = Is + ((wv * 4) * IW + l15) * IKP + 8 * kq;   // all 72 A-fragment reads are this base + an immediate
+        const T* Ib = Is + ((wv * RW) * IW + l15) * IKP + 8 * kq;   // all 72 A-fragment reads are this base + an immediate
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -428,7 +620,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             }
         }
         // D^T[row = channel t*16 + kq*4 + r][col = pixel l15]: pack to bf16, accumulate the BN statistics of valid outputs
-        const bool full = h0 + TH <= H && w0 + TW <= W && co0 + COT <= Cout;
+        const bool full = h0 + THS <= H && w0 + TW <= W && co0 + COT <= Cout;
         if (POOL) {
 #pragma unroll
             for (int mp = 0; mp < MPK; ++mp) {
@@ -450,7 +642,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            const int h = h0 + wv * 4 + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+            const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
             const bool ok = full || (h < H && w < W);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -459,16 +651,20 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[m][t][r];
                     e[r] = from_f32<T>(v);
-                    const float vv = (full || (ok && co0 + t * 16 + kq * 4 + r < Cout)) ? v : 0.f;
-                    s1[t][r] += vv;
-                    s2[t][r] += vv * vv;
+                    if (!RED) {
+                        const float vv = (full || (ok && co0 + t * 16 + kq * 4 + r < Cout)) ? v : 0.f;
+                        s1[t][r] += vv;
+                        s2[t][r] += vv * vv;
+                    }
                 }
                 pk[m][t] = *reinterpret_cast<const uint2*>(e);
             }
         }
         ptile = tile;
+        if (RED) load_red(tile);               // in flight across the next commit, consumed by store_prev
     }
     if (ptile >= 0) store_prev();
+    if (RED) stats = br.parts;
     if (stats) {   // one part per block (zero for a block without tiles)
         __shared__ float sred[4][2][COT];
 #pragma unroll
@@ -485,10 +681,12 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             }
         __syncthreads();
         if (tid < COT && co0 + tid < Cout) {
+            float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+            if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
             store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid]);
-            store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid]);
+            store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
         }
-        if (fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {
+        if (!RED && fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {
             bn_finish_block(stats, (int)gridDim.x, Cout, fin, reinterpret_cast<float*>(smem));
             last_block_done(fin.counter);
         }
@@ -539,9 +737,11 @@ __global__ __launch_bounds__(256) void pack_w_multi_kernel(const PackJob* __rest
 // block = (co tile 32, ci chunk 32, split); wave = 2 of the tile's 8 rows; acc 2 x 18 tiles.
 constexpr int WG_TH = 8, WG_TW = 32, WG_P = 34;  // tile rows / cols, LDS channel stride (32 + 2)
 
-template <typename T>
+// BNL (all three weight-gradient kernels): `gout` is the layer's raw convolution output and bl.gy the gradient of its activation; the
+// loader forms graw (common.h, bn_graw_vec) -- positions outside the image stay zero.
+template <typename T, bool BNL = false>
 __global__ __launch_bounds__(kCT, 1) void conv3x3_wgrad_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ gout, int Cout,
-                                                              int nsplit, float* __restrict__ partials) {
+                                                              int nsplit, float* __restrict__ partials, BnLoad bl) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float* Gs = wsm;                                   // [WG_TH*WG_TW][WG_P]
     float* Is = wsm + WG_TH * WG_TW * WG_P;            // [(WG_TH+2)*(WG_TW+2)][WG_P]
@@ -556,6 +756,10 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_wgrad_kernel(ConvSrc src, int 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 18; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bc[kBwdCoefRows] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // BNL: this thread's channel (tid & 31) in every element it loads
+    if (BNL && co0 + (tid & 31) < Cout)
+#pragma unroll
+        for (int r = 0; r < kBwdCoefRows; ++r) bc[r] = bl.coef[(size_t)r * Cout + co0 + (tid & 31)];
 
     for (int tile = split; tile < ntiles; tile += nsplit) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
@@ -565,7 +769,15 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_wgrad_kernel(ConvSrc src, int 
             const int c = idx & 31, px = idx >> 5, ix = px % WG_TW, iy = px / WG_TW;
             const int h = h0 + iy, w = w0 + ix;
             float v = 0.f;
-            if (h < H && w < W && co0 + c < Cout) v = to_f32(gout[(((size_t)n * H + h) * W + w) * Cout + co0 + c]);
+            if (h < H && w < W && co0 + c < Cout) {
+                const size_t o = (((size_t)n * H + h) * W + w) * Cout + co0 + c;
+                v = to_f32(gout[o]);
+                if (BNL) {
+                    const float g = to_f32(reinterpret_cast<const T*>(bl.gy)[o]);
+                    const float lin = bc[4] + bc[5] * (v - bc[2]);
+                    v = v * bc[0] + bc[1] > relu_keep_threshold<T>() ? bc[3] * g + lin : lin;
+                }
+            }
             Gs[px * WG_P + c] = v;
         }
         for (int idx = tid; idx < (WG_TH + 2) * IW * 32; idx += kCT) {
@@ -653,8 +865,9 @@ __device__ __forceinline__ bf16x8_t tr_frag(const short* blk_px0, int q, int p) 
     return __builtin_bit_cast(bf16x8_t, f);
 }
 
+template <bool BNL>
 __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ gout,
-                                                                   int Cout, int nsplit, float* __restrict__ partials) {
+                                                                   int Cout, int nsplit, float* __restrict__ partials, BnLoad bl) {
     constexpr int IW = WG_TW + 2, NPX = WG_TH * WG_TW, NIPX = (WG_TH + 2) * IW;
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
     // The two 16-channel sub-tiles of a half-wave's transpose read (lanes 0-15 | 16-31) must land in different 128-byte bank windows:
@@ -691,15 +904,27 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
     // next tile's operands travel global -> registers while the current tile is on the matrix cores
     constexpr int NG = NPX * 4 / kCT, NI = (NIPX * 4 + kCT - 1) / kCT;
     uint4 pg[NG], pi[NI];
-    auto fetch = [&](int tile) {
+    uint4 pr[BNL ? NG : 1];                                 // BNL: pg = activation gradient, pr = raw output, okg = slots inside the image
+    unsigned okg = 0;
+    float* Cf = reinterpret_cast<float*>(Is + 2 * NIPX * 16);   // BNL: [6][32] loader coefficients behind the operand tiles
+    if (BNL) {
+        for (int idx = tid; idx < kBwdCoefRows * 32; idx += kCT) Cf[idx] = co0 + (idx & 31) < Cout ? bl.coef[(size_t)(idx >> 5) * Cout + co0 + (idx & 31)] : 0.f;
+        __syncthreads();
+    }
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
         const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+        okg = 0;
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, ix = px % WG_TW, iy = px / WG_TW;
             const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
             uint4 val = zero4;
-            if (h < H && w < W && c < Cout) val = *reinterpret_cast<const uint4*>(gout + (((size_t)n * H + h) * W + w) * Cout + c);
+            if (h < H && w < W && c < Cout) {
+                const size_t o = (((size_t)n * H + h) * W + w) * Cout + c;
+                if (BNL) { pr[j] = *reinterpret_cast<const uint4*>(gout + o); val = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(bl.gy) + o); okg |= 1u << j; }
+                else val = *reinterpret_cast<const uint4*>(gout + o);
+            }
             pg[j] = val;
         }
 #pragma unroll
@@ -724,6 +949,20 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
     if (split < ntiles) fetch(split);
     for (int tile = split; tile < ntiles; tile += nsplit) {
         __syncthreads();
+        if (BNL) {
+            asm volatile("" ::: "memory");
+            float cf[kBwdCoefRows][8];
+#pragma unroll
+            for (int r = 0; r < kBwdCoefRows; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; i += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(Cf + r * 32 + (tid & 3) * 8 + i);
+                    cf[r][i] = q.x; cf[r][i + 1] = q.y; cf[r][i + 2] = q.z; cf[r][i + 3] = q.w;
+                }
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                pg[j] = (okg >> j) & 1u ? bn_graw_vec<bf16>(pr[j], pg[j], cf[0], cf[1], cf[2], cf[3], cf[4], cf[5]) : zero4;
+        }
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2;
@@ -786,8 +1025,9 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
 // 16-channel slice of the input (grid.y), v_mfma_f32_16x16x32_bf16 (k = the 32 pixels of a tile row), 36 accumulator
 // registers instead of 144 and 19 KB of LDS instead of 38 -> ~5 blocks per CU keep enough loads in flight to stream.
 // Writes the same partial layout as conv3x3_wgrad_bf16_kernel (its 16 x 9 x 16 corner of the 32 x 288 tile).
-__global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ gout,
-                                                                       int Cout, int nsplit, float* __restrict__ partials) {
+template <bool BNL>
+__global__ __launch_bounds__(kCT, BNL ? 3 : 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc src, int N, int H, int W, const bf16* __restrict__ gout,
+                                                                       int Cout, int nsplit, float* __restrict__ partials, BnLoad bl) {
     constexpr int IW = WG_TW + 2, NPX = WG_TH * WG_TW, NIPX = (WG_TH + 2) * IW;
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
     short* Gs = reinterpret_cast<short*>(wsm_raw);            // [NPX][16]
@@ -804,15 +1044,27 @@ __global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc 
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     constexpr int NG = NPX * 2 / kCT, NI = (NIPX * 2 + kCT - 1) / kCT;
     uint4 pg[NG], pi[NI];
-    auto fetch = [&](int tile) {
+    uint4 pr[BNL ? NG : 1];
+    unsigned okg = 0;
+    float* Cf = reinterpret_cast<float*>(Is + NIPX * 16);       // BNL: [6][16] loader coefficients behind the operand tiles
+    if (BNL) {
+        for (int idx = tid; idx < kBwdCoefRows * 16; idx += kCT) Cf[idx] = co0 + (idx & 15) < Cout ? bl.coef[(size_t)(idx >> 4) * Cout + co0 + (idx & 15)] : 0.f;
+        __syncthreads();
+    }
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
         const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+        okg = 0;
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, ix = px % WG_TW, iy = px / WG_TW;
             const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
             uint4 val = zero4;
-            if (h < H && w < W && c < Cout) val = *reinterpret_cast<const uint4*>(gout + (((size_t)n * H + h) * W + w) * Cout + c);
+            if (h < H && w < W && c < Cout) {
+                const size_t o = (((size_t)n * H + h) * W + w) * Cout + c;
+                if (BNL) { pr[j] = *reinterpret_cast<const uint4*>(gout + o); val = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(bl.gy) + o); okg |= 1u << j; }
+                else val = *reinterpret_cast<const uint4*>(gout + o);
+            }
             pg[j] = val;
         }
 #pragma unroll
@@ -837,6 +1089,20 @@ __global__ __launch_bounds__(kCT, 4) void conv3x3_wgrad_bf16_c16_kernel(ConvSrc 
     if (split < ntiles) fetch(split);
     for (int tile = split; tile < ntiles; tile += nsplit) {
         __syncthreads();
+        if (BNL) {
+            asm volatile("" ::: "memory");
+            float cf[kBwdCoefRows][8];
+#pragma unroll
+            for (int r = 0; r < kBwdCoefRows; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; i += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(Cf + r * 16 + (tid & 1) * 8 + i);
+                    cf[r][i] = q.x; cf[r][i + 1] = q.y; cf[r][i + 2] = q.z; cf[r][i + 3] = q.w;
+                }
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                pg[j] = (okg >> j) & 1u ? bn_graw_vec<bf16>(pr[j], pg[j], cf[0], cf[1], cf[2], cf[3], cf[4], cf[5]) : zero4;
+        }
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + kCT * j;
@@ -1062,9 +1328,53 @@ static bool sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t
     return conv_streams(dt, Cin, N, H, W) || (dt == MISEG_BF16 && Cout > 32);
 }
 
+// One tile shape of the tiled kernel / one slot layout of the streaming kernel in the forms a call can ask for: plain, BN loader,
+// epilogue reduce, both (the pooled-output forms: plain and BN loader).
+template <typename TT, int COT, int TWW, int THH, bool POOL>
+static void launch_tiled(dim3 grid, hipStream_t st, const ConvSrc& s, int N, int H, int W, const void* wpk, int Cout, void* out, float* stats,
+                         const BnFinish& fin, const BnLoad& bl, const BnRed& br) {
+    const size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);
+#define GO(BNL, RED)                                                                                                                 \
+    {                                                                                                                               \
+        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED>), grid, dim3(kCT), lb, st, s, N, H, W, (const TT*)wpk, Cout,  \
+                           (TT*)out, stats, fin, bl, br);                                                                           \
+    }
+    if constexpr (POOL) { if (bl.gy) GO(true, false) else GO(false, false) }
+    else { if (bl.gy && br.raw) GO(true, true) else if (bl.gy) GO(true, false) else if (br.raw) GO(false, true) else GO(false, false) }
+#undef GO
+}
+// rows per wave of the streaming kernel's fused forms (see the kernel): 2 unless 16 gradient channels meet 16 outputs or a pooled output
+template <int COT, int NV, bool POOL> constexpr int fused_rw() { return (NV == 2 && (COT == 16 || POOL)) ? 4 : 2; }
+template <int COT, int NV, bool DU, bool POOL>
+static int launch_stream(unsigned blocks, hipStream_t st, const ConvSrc& s, int N, int H, int W, const void* wpk, int Cout, void* out, float* stats,
+                         const BnFinish& fin, const BnLoad& bl, const BnRed& br) {
+    const dim3 grid(blocks, (unsigned)cdiv(Cout, COT));
+#define GO(BNL, RED, RWW)                                                                                                            \
+    {                                                                                                                               \
+        const size_t lb = ((size_t)(4 * RWW + 2) * (32 + 2) * (COT == 16 ? 48 : Mma<bf16>::CKP) + 9 * COT * Mma<bf16>::CKP) * sizeof(bf16) + \
+                          (BNL ? kBwdCoefRows * CK * 4 : 0) + (RED ? 3 * COT * 4 : 0);                                               \
+        const int ntiles = (int)(N * cdiv(H, 4 * RWW) * cdiv(W, 32));                                                                \
+        hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, DU, POOL, BNL, RED, RWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, DU, POOL, BNL, RED, RWW>), grid, dim3(kCT), lb, st, s, N, H, W,          \
+                           (const bf16*)wpk, Cout, (bf16*)out, stats, ntiles, fin, bl, br);                                          \
+    }
+    constexpr bool kFusable = !DU && (NV == 2 || NV == 4);      // the data-gradient shapes of the U-Net: 16 or 32 gradient channels
+    if constexpr (kFusable) {
+        constexpr int FRW = fused_rw<COT, NV, POOL>();
+        if constexpr (POOL) { if (bl.gy) GO(true, false, FRW) else GO(false, false, 4) }
+        else { if (bl.gy && br.raw) GO(true, true, FRW) else if (bl.gy) GO(true, false, FRW) else if (br.raw) GO(false, true, FRW) else GO(false, false, 4) }
+    } else {
+        if (bl.gy || br.raw) return fail(MISEG_E_INVALID, "conv3x3: BatchNorm loader / reduce not built for this streaming shape");
+        GO(false, false, 4)
+    }
+#undef GO
+    return MISEG_OK;
+}
+
 static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                             int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats, BnFinish fin,
-                            bool pool_out = false) {
+                            bool pool_out = false, BnLoad bl = BnLoad{nullptr, nullptr}, BnRed br = BnRed{nullptr, nullptr, nullptr}) {
     MISEG_REQUIRE(in0 && packed_w && out, "conv3x3_fwd: null pointer");
     MISEG_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0, "conv3x3_fwd: bad shape");
     MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_fwd: second source missing");
@@ -1077,30 +1387,21 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
     const int th = conv_streams(dt, C0 + C1, N, H, W) ? TH : generic_tile_h(dt, H, W);
     const unsigned gx = (unsigned)(N * cdiv(H, th) * cdiv(W, tw));
     hipStream_t st = as_stream(stream);
+    MISEG_REQUIRE(!bl.gy || (bl.coef && C1 == 0 && ups0 == 0), "conv3x3: the BatchNorm loader reads one full-resolution source");
+    MISEG_REQUIRE(!br.raw || (br.saved && br.parts && !pool_out && !stats && Cout % 4 == 0), "conv3x3: epilogue reduce needs a full-resolution "
+                  "output with a multiple of 4 channels and no forward statistics");
 #define LAUNCH_TH(TT, COT, TWW, THH)                                                                                       \
-    {                                                                                                                     \
-        size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);                                  \
-        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH>), dim3(gx, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
-                           (int)W, (const TT*)packed_w, (int)Cout, (TT*)out, stats, fin);                                  \
-    }
+    launch_tiled<TT, COT, TWW, THH, false>(dim3(gx, (unsigned)cdiv(Cout, COT)), st, s, (int)N, (int)H, (int)W, packed_w, (int)Cout, out, stats, fin, bl, br);
 #define LAUNCH(TT, COT, TWW) { if (th == 8) LAUNCH_TH(TT, COT, TWW, 8) else LAUNCH_TH(TT, COT, TWW, 16) }
     MISEG_REQUIRE(!pool_out || (sumpool_supported(dt, C0 + C1, N, H, W, Cout) && C1 == 0 && !stats),
                   "conv3x3_fwd_sumpool: shape not supported (ask miseg_conv3x3_fwd_sumpool_supported)");
     if (conv_streams(dt, C0 + C1, N, H, W)) {
+        int rc = MISEG_OK;
 #define SLAUNCH(COT, NV, DU)                                                                                               \
     {                                                                                                                     \
-        size_t lb = ((size_t)(TH + 2) * (32 + 2) * (COT == 16 ? 48 : Mma<bf16>::CKP) + 9 * COT * Mma<bf16>::CKP) * sizeof(bf16);      \
         const unsigned g = (unsigned)stream_blocks(N, H, W);                                                               \
-        if (pool_out && !DU) {                                                                                           \
-            hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-            hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, false, true>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, \
-                               (int)H, (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx, fin);              \
-        } else {                                                                                                         \
-        hipFuncSetAttribute((const void*)conv3x3_stream_kernel<COT, 32, NV, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-        hipLaunchKernelGGL((conv3x3_stream_kernel<COT, 32, NV, DU>), dim3(g, (unsigned)cdiv(Cout, COT)), dim3(kCT), lb, st, s, (int)N, (int)H, \
-                           (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, (int)gx, fin);                      \
-        }                                                                                                                \
+        if (pool_out && !DU) rc = launch_stream<COT, NV, false, true>(g, st, s, (int)N, (int)H, (int)W, packed_w, (int)Cout, out, stats, fin, bl, br); \
+        else rc = launch_stream<COT, NV, DU, false>(g, st, s, (int)N, (int)H, (int)W, packed_w, (int)Cout, out, stats, fin, bl, br); \
     }
 #define SLAUNCH_NV(COT)                                                                                                    \
     {                                                                                                                     \
@@ -1113,14 +1414,10 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
         else SLAUNCH_NV(32)
 #undef SLAUNCH_NV
 #undef SLAUNCH
+        if (rc != MISEG_OK) return rc;
     } else if (dt == MISEG_BF16 && pool_out) {
 #define LAUNCH_P(TWW, THH)                                                                                                 \
-    {                                                                                                                     \
-        size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * 64) * Mma<bf16>::KP * sizeof(bf16);                               \
-        hipFuncSetAttribute((const void*)conv3x3_kernel<bf16, 64, TWW, THH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-        hipLaunchKernelGGL((conv3x3_kernel<bf16, 64, TWW, THH, true>), dim3(gx, (unsigned)cdiv(Cout, 64)), dim3(kCT), lb, st, s, (int)N, (int)H, \
-                           (int)W, (const bf16*)packed_w, (int)Cout, (bf16*)out, stats, fin);                               \
-    }
+    launch_tiled<bf16, 64, TWW, THH, true>(dim3(gx, (unsigned)cdiv(Cout, 64)), st, s, (int)N, (int)H, (int)W, packed_w, (int)Cout, out, stats, fin, bl, br);
         if (tw == 32) { if (th == 8) LAUNCH_P(32, 8) else LAUNCH_P(32, 16) }
         else { if (th == 8) LAUNCH_P(16, 8) else LAUNCH_P(16, 16) }
 #undef LAUNCH_P
@@ -1167,6 +1464,34 @@ extern "C" int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* i
     return conv3x3_fwd_impl(stream, dt, in, Cin, 0, nullptr, 0, 0, N, H, W, packed_w, Cout, inout_pooled, nullptr, opt, true);
 }
 
+// ---- data gradient with the BatchNorm backward folded in (unet_ops._ConvBNReLU.backward)
+static bool dgrad_bn_stream_ok(int dt, int64_t K, int64_t N, int64_t H, int64_t W) {
+    return !conv_streams(dt, K, N, H, W) || K == 16 || K == 32;
+}
+extern "C" int64_t miseg_conv3x3_dgrad_bn_supported(int dt, int64_t K, int64_t N, int64_t H, int64_t W, int64_t Cs, int pool_out) {
+    if (dt == MISEG_F16) dt = MISEG_BF16;
+    const int vec = dt == MISEG_BF16 ? 8 : 4;
+    if (K % vec || !dgrad_bn_stream_ok(dt, K, N, H, W)) return 0;
+    return pool_out ? sumpool_supported(dt, K, N, H, W, Cs) : 1;
+}
+extern "C" int64_t miseg_conv3x3_dgrad_red_parts(int dt, int64_t K, int64_t N, int64_t H, int64_t W, int64_t Cs) {
+    if (dt == MISEG_F16) dt = MISEG_BF16;
+    if (Cs % 4 || !dgrad_bn_stream_ok(dt, K, N, H, W)) return 0;
+    return miseg_conv3x3_stats_parts(dt, K, N, H, W);
+}
+extern "C" int miseg_conv3x3_dgrad_bn(void* stream, int dt, const void* raw_or_graw, const void* gy, const float* bwd_coef, int64_t K,
+                                      int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cs, void* out, int pool_out,
+                                      const void* red_raw, const float* red_saved, float* red_parts) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_dgrad_bn, stream, MISEG_BF16, raw_or_graw, gy, bwd_coef, K, N, H, W, packed_w, Cs, out, pool_out, red_raw,
+                          red_saved, red_parts);
+    MISEG_REQUIRE(!gy || bwd_coef, "conv3x3_dgrad_bn: coefficients missing");
+    MISEG_REQUIRE(!red_raw || (!pool_out && red_saved && red_parts && miseg_conv3x3_dgrad_red_parts(dt, K, N, H, W, Cs) > 0),
+                  "conv3x3_dgrad_bn: epilogue reduce not available for this call (ask miseg_conv3x3_dgrad_red_parts)");
+    MISEG_REQUIRE(!gy || miseg_conv3x3_dgrad_bn_supported(dt, K, N, H, W, Cs, pool_out), "conv3x3_dgrad_bn: shape not supported (ask _supported)");
+    return conv3x3_fwd_impl(stream, dt, raw_or_graw, K, 0, nullptr, 0, 0, N, H, W, packed_w, Cs, out, nullptr, BnFinish{}, pool_out != 0,
+                            BnLoad{gy, bwd_coef}, BnRed{red_raw, red_saved, red_parts});
+}
+
 // The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.
 static const int64_t kBnFinishMaxFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
 
@@ -1203,9 +1528,8 @@ extern "C" int64_t miseg_conv3x3_wgrad_ws_bytes(int64_t N, int64_t H, int64_t W,
     return (int64_t)wgrad_splits(N, H, W, Cin, Cout) * cdiv(Cin, 32) * cdiv(Cout, 32) * 32 * 288 * 4;
 }
 
-extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
-                                   int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
-    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_wgrad, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes);
+static int conv3x3_wgrad_impl(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1, int64_t N,
+                              int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw, void* ws, int64_t ws_bytes, BnLoad bl) {
     MISEG_REQUIRE(in0 && gout && gw && ws, "conv3x3_wgrad: null pointer");
     MISEG_REQUIRE(C1 == 0 || in1, "conv3x3_wgrad: second source missing");
     const int64_t Cin = C0 + C1;
@@ -1216,8 +1540,13 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
     hipStream_t st = as_stream(stream);
     dim3 grid(ns, nci, nco);
     if (dt == MISEG_F32) {
-        hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<float>, grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws);
+        if (bl.gy) {
+            hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, true>), grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws, bl);
+        } else {
+            hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, false>), grid, dim3(kCT), lb, st, s, (int)N, (int)H, (int)W, (const float*)gout, (int)Cout, ns, (float*)ws, bl);
+        }
     } else if (dt == MISEG_BF16) {
         MISEG_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "conv3x3_wgrad: bf16 needs channel counts that are multiples of 8");
         const size_t lbb = std::max<size_t>(((size_t)2 * WG_TH * WG_TW + 2 * (WG_TH + 2) * (WG_TW + 2)) * 16 * 2 + 2 * 64 * 2, (size_t)(32 * 288 + 4 * 1024) * 4);
@@ -1226,12 +1555,16 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
         // from 32->32 up the 32x32-tile kernel's operand reuse wins
         const bool narrow = Cout % 16 == 0 && (std::min(Cin, Cout) <= 16 || (Cin == 32 && Cout == 64));
         if (narrow || Cout <= 16) {
-            const size_t lbc = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * 16 * 2;
+            const size_t lbc = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * 16 * 2 + (bl.gy ? kBwdCoefRows * 16 * 4 : 0);
             dim3 gridc(ns, (unsigned)cdiv(Cin, 16), (unsigned)cdiv(Cout, 16));
-            hipLaunchKernelGGL(conv3x3_wgrad_bf16_c16_kernel, gridc, dim3(kCT), lbc, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
+            if (bl.gy) hipLaunchKernelGGL(conv3x3_wgrad_bf16_c16_kernel<true>, gridc, dim3(kCT), lbc, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws, bl);
+            else hipLaunchKernelGGL(conv3x3_wgrad_bf16_c16_kernel<false>, gridc, dim3(kCT), lbc, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws, bl);
+        } else if (bl.gy) {
+            hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbb);
+            hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<true>, grid, dim3(kCT), lbb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws, bl);
         } else {
-        hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbb);
-        hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, grid, dim3(kCT), lbb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws);
+            hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbb);
+            hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<false>, grid, dim3(kCT), lbb, st, s, (int)N, (int)H, (int)W, (const bf16*)gout, (int)Cout, ns, (float*)ws, bl);
         }
     } else return fail(MISEG_E_INVALID, "conv3x3_wgrad: bad dtype");
     MISEG_LAUNCH_CHECK("conv3x3_wgrad_kernel");
@@ -1239,6 +1572,21 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(total, ns)), dim3(256), 0, st, (const float*)ws, ns, (int)Cout, (int)Cin, nco, nci, gw);
     MISEG_LAUNCH_CHECK("wgrad_reduce_kernel");
     return MISEG_OK;
+}
+
+extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                   int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_wgrad, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes);
+    return conv3x3_wgrad_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes, BnLoad{nullptr, nullptr});
+}
+
+extern "C" int miseg_conv3x3_wgrad_bn(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                      int64_t N, int64_t H, int64_t W, const void* raw, const void* gy, const float* bwd_coef, int64_t Cout,
+                                      float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_wgrad_bn, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, raw, gy, bwd_coef, Cout, gw, ws, ws_bytes);
+    MISEG_REQUIRE(gy && bwd_coef, "conv3x3_wgrad_bn: null pointer");
+    MISEG_REQUIRE(Cout % (dt == MISEG_F32 ? 4 : 8) == 0, "conv3x3_wgrad_bn: Cout must be a whole number of 16-byte vectors");
+    return conv3x3_wgrad_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, raw, Cout, gw, ws, ws_bytes, BnLoad{gy, bwd_coef});
 }
 
 extern "C" int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t Cin, const float* w,

@@ -48,6 +48,32 @@ def join_wgrad_streams() -> None:
 
 
 _FUSE_UPS_DGRAD = True   # False: conv3x3 dgrad + miseg_sumpool2x2 as two launches
+# BatchNorm backward folded into the convolutions around it (layers without the fused pool): the statistics pass leaves six
+# coefficients per channel, the data- and weight-gradient kernels form graw in their loaders (no bn_bwd_apply pass, no graw tensor),
+# and a data-gradient launch whose output is the activation gradient of ANOTHER such layer takes that layer's statistics pass in its
+# epilogue (no bn_relu_bwd_reduce pass there).  MISEG_BN_FUSE=0: the three-pass form everywhere.
+_FUSE_BN_BWD = os.environ.get("MISEG_BN_FUSE", "0") == "1"
+_FUSE_BN_RED = os.environ.get("MISEG_BN_FUSE_RED", "1") != "0"
+
+
+class _BnRec:
+    """What a layer's CONSUMER needs to take the layer's BatchNorm-backward sums in the epilogue of its data-gradient kernel, and
+    the hand-over of those sums.  Hangs off the activation tensor (``y._miseg_bn``); the consumer's backward fills ``parts`` and
+    names the gradient tensor they belong to, the layer's backward uses them only if autograd hands it that very tensor, unmodified
+    (another consumer of the activation -> autograd added the gradients into a new tensor -> the ordinary reduce runs)."""
+    __slots__ = ("raw", "saved", "shape", "parts", "nparts", "for_grad", "for_version")
+
+    def __init__(self):
+        self.raw = self.saved = self.shape = self.parts = self.for_grad = None
+        self.nparts = self.for_version = 0
+
+    def offer(self, grad: Tensor, parts: Tensor, nparts: int) -> None:
+        self.parts, self.nparts, self.for_grad, self.for_version = parts, nparts, grad, grad._version
+
+    def take(self, grad: Optional[Tensor]):
+        parts, nparts, mine = self.parts, self.nparts, self.for_grad is grad and grad is not None and grad._version == self.for_version
+        self.parts = self.for_grad = None
+        return (parts, nparts) if mine and parts is not None else (None, 0)
 
 
 class _SyncCounters:
@@ -198,7 +224,8 @@ def _pack(weight: Tensor, dtype, kind: int, ci_begin: int = 0, ci_count: int = 0
 class _ConvBNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor,
-                running_var: Tensor, nbt: Tensor, training: bool, ups0: int, ups1: int, want_pool: bool):
+                running_var: Tensor, nbt: Tensor, training: bool, ups0: int, ups1: int, want_pool: bool, rec: Optional[_BnRec] = None,
+                rec0: Optional[_BnRec] = None, rec1: Optional[_BnRec] = None):
         _need_gpu(x0, x1, weight)
         x0 = as_nhwc(x0)
         dtype, dev = x0.dtype, x0.device
@@ -242,6 +269,9 @@ class _ConvBNReLU(torch.autograd.Function):
         ctx.save_for_backward(x0, x1, weight, gamma, raw, y, saved)
         ctx.param_refs = (weight, gamma, beta)   # the Parameter objects (flat-gradient slots hang off them)
         ctx.cfg = (training, ups0, ups1, want_pool, c0, c1, n, h, w, cout)
+        if rec is not None:
+            rec.raw, rec.saved, rec.shape = raw, saved, (n, cout, h, w)
+        ctx.recs = (rec, rec0, rec1)
         if want_pool:
             return y, pooled
         return y, None
@@ -252,7 +282,11 @@ class _ConvBNReLU(torch.autograd.Function):
         training, ups0, ups1, want_pool, c0, c1, n, h, w, cout = ctx.cfg
         dtype, dev = raw.dtype, raw.device
         if gy is None and gpool is None:
-            return (None,) * 12
+            return (None,) * 15
+        rec, rec0, rec1 = ctx.recs
+        ext_parts, ext_nparts = rec.take(gy) if rec is not None else (None, 0)
+        if _FUSE_BN_BWD and not want_pool and gpool is None and gy is not None and _dgrads_fusable(ctx, dtype):
+            return _ConvBNReLU._backward_fused(ctx, gy, ext_parts, ext_nparts)
         gy = None if gy is None else as_nhwc(gy.to(dtype))
         gpool = None if gpool is None else as_nhwc(gpool.to(dtype))
         graw = empty_nhwc(n, cout, h, w, dtype, dev)
@@ -323,6 +357,16 @@ class _ConvBNReLU(torch.autograd.Function):
                 grads[s] = glow
                 continue
             gfull = empty_nhwc(n, cs, h, w, dtype, dev)
+            src_rec = (rec0, rec1)[s]
+            red = _red_target(src_rec, ups, dtype, cout, n, h, w, cs)
+            if red is not None:      # the source is a BatchNorm layer read at full resolution: its backward sums in this launch's epilogue
+                parts, nparts = red
+                call("miseg_conv3x3_dgrad_bn", _stream(), _DT[dtype], _ptr(graw), None, None, cout, n, h, w, _ptr(packed), cs, _ptr(gfull), 0,
+                     _ptr(src_rec.raw), _ptr(src_rec.saved), _ptr(parts),
+                     work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (2 * cs + cout)), tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+                src_rec.offer(gfull, parts, nparts)
+                grads[s] = gfull
+                continue
             call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(graw), cout, 0, None, 0, 0, n, h, w, _ptr(packed), cs, _ptr(gfull), None,
                  work=(18.0 * cs * cout * n * h * w, float(raw.element_size()) * n * h * w * (cs + cout)), tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
             if ups:
@@ -330,14 +374,115 @@ class _ConvBNReLU(torch.autograd.Function):
                 call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)
                 gfull = glow
             grads[s] = gfull
-        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None
+        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_fused(ctx, gy_in: Tensor, ext_parts: Optional[Tensor], ext_nparts: int):
+        x0, x1, weight, gamma, raw, y, saved = ctx.saved_tensors
+        training, ups0, ups1, want_pool, c0, c1, n, h, w, cout = ctx.cfg
+        rec, rec0, rec1 = ctx.recs
+        dtype, dev, es = raw.dtype, raw.device, raw.element_size()
+        gy = as_nhwc(gy_in.to(dtype))
+        pw, pg, pb = ctx.param_refs
+        ggamma, gbeta = grad_slot(pg), grad_slot(pb)
+        if ggamma is None:
+            ggamma = torch.empty(cout, dtype=torch.float32, device=dev)
+        if gbeta is None:
+            gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+        coef = torch.empty(6 * cout, dtype=torch.float32, device=dev)
+        if ext_parts is not None:       # the consumer's data-gradient kernel already summed dz and dz * xhat per block: finalize only
+            call("miseg_bn_relu_bwd_stats", _stream(), _DT[dtype], None, None, n, h, w, cout, _ptr(gamma), _ptr(saved), int(training), _ptr(coef),
+                 _ptr(ggamma), _ptr(gbeta), _ptr(ext_parts), ext_nparts, None, 0)
+        else:
+            ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
+            call("miseg_bn_relu_bwd_stats", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), n, h, w, cout, _ptr(gamma), _ptr(saved), int(training),
+                 _ptr(coef), _ptr(ggamma), _ptr(gbeta), None, 0, _ptr(ws), ws.numel(),
+                 work=(0.0, float(es) * n * h * w * cout * 2.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
+        gw = None
+        if ctx.needs_input_grad[2]:
+            gw = grad_slot(pw)
+            side = None
+            if gw is None:
+                gw = torch.empty_like(weight)
+            elif _WGRAD_SIDE and (_GRAPH_STREAMS or not torch.cuda.is_current_stream_capturing()):
+                side = wgrad_stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            if side is not None:
+                if not _wgrad_dirty:
+                    torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
+                side.wait_stream(cur)         # coef is produced above
+                for t in (raw, gy, coef, x0, x1):
+                    if t is not None:
+                        t.record_stream(side)
+                _wgrad_dirty.add(dev)
+            with torch.cuda.stream(side if side is not None else cur):
+                ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
+                call("miseg_conv3x3_wgrad_bn", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(raw), _ptr(gy), _ptr(coef),
+                     cout, _ptr(gw), _ptr(ws2), ws2.numel(),
+                     work=(18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 + c1 + 2 * cout)), tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
+        grads = [None, None]
+        for s, (cb, cs, ups, xs, src_rec) in enumerate(((0, c0, ups0, x0, rec0), (c0, c1, ups1, x1, rec1))):
+            if xs is None or not ctx.needs_input_grad[s]:
+                continue
+            packed = _pack(weight, dtype, 1, cb, cs)
+            flops = 18.0 * cs * cout * n * h * w
+            pooled = bool(ups) and bool(query("miseg_conv3x3_dgrad_bn_supported", _DT[dtype], cout, n, h, w, cs, 1))
+            if pooled:
+                glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
+                call("miseg_conv3x3_dgrad_bn", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), _ptr(coef), cout, n, h, w, _ptr(packed), cs, _ptr(glow), 1,
+                     None, None, None, work=(flops, float(es) * n * h * w * (cs / 4 + 2 * cout)), tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+                grads[s] = glow
+                continue
+            gfull = empty_nhwc(n, cs, h, w, dtype, dev)
+            red = _red_target(src_rec, ups, dtype, cout, n, h, w, cs)
+            if red is not None:
+                parts, nparts = red
+                call("miseg_conv3x3_dgrad_bn", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), _ptr(coef), cout, n, h, w, _ptr(packed), cs, _ptr(gfull), 0,
+                     _ptr(src_rec.raw), _ptr(src_rec.saved), _ptr(parts), work=(flops, float(es) * n * h * w * (2 * cs + 2 * cout)),
+                     tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+                src_rec.offer(gfull, parts, nparts)
+            else:
+                call("miseg_conv3x3_dgrad_bn", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), _ptr(coef), cout, n, h, w, _ptr(packed), cs, _ptr(gfull), 0,
+                     None, None, None, work=(flops, float(es) * n * h * w * (cs + 2 * cout)), tag=f"conv3x3_dgrad[{h}x{w},{cout}->{cs}]")
+            if ups:
+                glow = empty_nhwc(n, cs, h // 2, w // 2, dtype, dev)
+                call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)
+                gfull = glow
+            grads[s] = gfull
+        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
+
+
+def _dgrads_fusable(ctx, dtype) -> bool:
+    """Can every data-gradient launch of this layer's backward form graw in its loader?"""
+    from .ops import _GradJoin
+    training, ups0, ups1, want_pool, c0, c1, n, h, w, cout = ctx.cfg
+    if _GradJoin.enabled or cout % vec_of(dtype):
+        return False
+    return all(cs == 0 or query("miseg_conv3x3_dgrad_bn_supported", _DT[dtype], cout, n, h, w, cs, 0) for cs in (c0, c1))
+
+
+def _red_target(src_rec: Optional[_BnRec], ups: int, dtype, cout: int, n: int, h: int, w: int, cs: int):
+    """(parts, nparts) if this data-gradient launch can take the source layer's BatchNorm-backward sums in its epilogue."""
+    if not (_FUSE_BN_BWD and _FUSE_BN_RED) or src_rec is None or ups or src_rec.raw is None or src_rec.shape != (n, cs, h, w) or \
+            src_rec.raw.dtype != dtype:
+        return None
+    nparts = query("miseg_conv3x3_dgrad_red_parts", _DT[dtype], cout, n, h, w, cs)
+    if not nparts:
+        return None
+    return torch.empty(nparts * 2 * cs, dtype=torch.float32, device=src_rec.raw.device), nparts
 
 
 def conv_bn_relu(x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor,
                  running_var: Tensor, nbt: Tensor, training: bool, ups0: int = 0, ups1: int = 0,
                  want_pool: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    return _ConvBNReLU.apply(x0, x1, weight, gamma, beta, running_mean, running_var, nbt, bool(training), int(ups0), int(ups1),
-                             bool(want_pool))
+    rec = None if want_pool else _BnRec()      # a pooled layer's backward routes through the 2x2 windows: it keeps its own reduce
+    rec0 = getattr(x0, "_miseg_bn", None) if not ups0 else None
+    rec1 = getattr(x1, "_miseg_bn", None) if x1 is not None and not ups1 else None
+    y, pooled = _ConvBNReLU.apply(x0, x1, weight, gamma, beta, running_mean, running_var, nbt, bool(training), int(ups0), int(ups1),
+                                  bool(want_pool), rec, rec0, rec1)
+    if rec is not None and rec.raw is not None:
+        y._miseg_bn = rec
+    return y, pooled
 
 
 class _Conv1x1(torch.autograd.Function):
