@@ -275,6 +275,12 @@ int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin,
 int64_t miseg_conv3x3_fwd_sumpool_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
 int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
                                   const void* packed_w, int64_t Cout, void* inout_pooled);
+/* Data gradient of a convolution whose input was the channel concat of two full-resolution sources (torch.cat((skip, up), 1),
+ * unet.py:109-125): conv3x3_fwd over grad_out [N,H,W,K] with the dgrad pack of ALL C0 + C1 input channels (kind 1, ci_begin 0,
+ * ci_count C0 + C1), channels [0, C0) written to out0 [N,H,W,C0] and [C0, C0 + C1) to out1 [N,H,W,C1] -- one launch reads grad_out
+ * once where two sliced launches read it twice.  C0 a multiple of 16, C1 of 4. */
+int miseg_conv3x3_dgrad_dual(void* stream, int dt, const void* grad_out, int64_t K, int64_t N, int64_t H, int64_t W,
+                             const void* packed_w, int64_t C0, void* out0, int64_t C1, void* out1);
 /* conv3x3_fwd + bn_finalize in ONE launch (training mode): the block that finishes last sums the partial rows and writes
  * `saved` / the running statistics itself (same formulas as miseg_bn_finalize; the sums are combined in a different but fixed
  * order).  sync_counter: one int32 in device memory, 0 on entry, 0 again when the kernel ends -- the caller may hand the same

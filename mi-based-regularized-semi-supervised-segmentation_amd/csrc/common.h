@@ -262,6 +262,8 @@ struct BnFinish {
     const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt; float* saved;
     float count, eps, momentum;
     int accumulate_out;              // POOL epilogues of the conv kernels: add to the output tensor instead of storing (a gradient join)
+    void* out1; int split;           // full-resolution epilogues: output channels [split, Cout) go to out1 ([.., Cout - split]), [0, split) to
+                                     // out ([.., split]) -- the data gradient of a concat convolution, one launch for both sources
 };
 __device__ __forceinline__ void bn_finish_block(const float* __restrict__ parts, int nparts, int C, const BnFinish& f, float* lds) {
     const float* sums = block_column_sums(parts, nparts, 2 * C, lds);      // [sum | sum of squares] per channel

@@ -263,10 +263,13 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
     for (int m = 0; m < MTW; ++m) {
         const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
         const bool ok = h < H && w < W;
-        T* op = out + (((size_t)n * H + h) * W + w) * Cout;
+        const size_t px = ((size_t)n * H + h) * W + w;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int co = co0 + t * 16 + kq * 4;
+            // `op + co` is the lane's 4 channels; two destinations: a lane never straddles the split (a multiple of 4)
+            T* op = out + px * Cout;
+            if (fin.out1) op = co < fin.split ? out + px * fin.split : reinterpret_cast<T*>(fin.out1) + px * (Cout - fin.split) - fin.split;
             if (ok && co + 3 < Cout) {
                 T pk[4];
 #pragma unroll
@@ -564,13 +567,24 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             }
             return;
         }
-        T* ob = out + (((size_t)n * H + h0 + wv * RW) * W + w0 + l15) * Cout + co0 + kq * 4;
+        // per 16-channel tile t: where its lanes' 4 channels go and the pixel stride there (two destinations: fin.out1, see BnFinish;
+        // the split is a multiple of 16, so a tile never straddles it)
+        const size_t px0 = ((size_t)n * H + h0 + wv * RW) * W + w0 + l15;
+        T* ot[NT];
+        int ost[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = co0 + t * 16 + kq * 4;
+            if (!fin.out1) { ot[t] = out + px0 * Cout + c; ost[t] = Cout; }
+            else if (c < fin.split) { ot[t] = out + px0 * fin.split + c; ost[t] = fin.split; }
+            else { ot[t] = reinterpret_cast<T*>(fin.out1) + px0 * (Cout - fin.split) + c - fin.split; ost[t] = Cout - fin.split; }
+        }
         if (full) {
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    *reinterpret_cast<uint2*>(ob + ((size_t)(m / MTR) * W + (m % MTR) * 16) * Cout + t * 16) = pk[m][t];
+                    *reinterpret_cast<uint2*>(ot[t] + ((size_t)(m / MTR) * W + (m % MTR) * 16) * ost[t]) = pk[m][t];
         } else {
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
                         const T* e = reinterpret_cast<const T*>(&pk[m][t]);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (co0 + t * 16 + kq * 4 + r < Cout) ob[((size_t)(m / MTR) * W + (m % MTR) * 16) * Cout + t * 16 + r] = e[r];
+                            if (co0 + t * 16 + kq * 4 + r < Cout) ot[t][((size_t)(m / MTR) * W + (m % MTR) * 16) * ost[t] + r] = e[r];
                     }
                 }
             }
@@ -1309,7 +1323,7 @@ static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
 // tile height of the generic kernel (bf16): 8 rows from 64^2 upwards (smaller LDS tile -> two blocks per CU; measured
 // 128^2 64->32: 78 -> 64 us), 16 rows for the small deep layers (32^2: 8-row tiles cost 46 -> 55 us) and for exact fp32
 static int generic_tile_h(int dt, int64_t H, int64_t W) {
-    const int force = 0;
+    static const int force = [] { const char* e = getenv("MISEG_CONV_TH"); return e ? atoi(e) : 0; }();   // scratch sweeps
     if (dt != MISEG_BF16) return 16;
     if (force == 8 || force == 16) return force;
     return H * W >= 64 * 64 ? 8 : 16;
@@ -1422,8 +1436,12 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
         else { if (th == 8) LAUNCH_P(16, 8) else LAUNCH_P(16, 16) }
 #undef LAUNCH_P
     } else if (dt == MISEG_BF16) {
+        static const int cot_cap = [] { const char* e = getenv("MISEG_CONV_COT"); return e ? atoi(e) : 64; }();   // scratch sweeps
         if (Cout <= 16) { if (tw == 32) LAUNCH(bf16, 16, 32) else LAUNCH(bf16, 16, 16) }
-        else if (Cout <= 32) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
+        // 8-row tiles (maps from 64^2 up) take 32 output channels per block: with 64 the weight chunk makes the block's LDS 88 KB -- one
+        // block per CU --, with 32 it is 60 KB and two fit (64^2, same box: 32->64 31.8 -> 26.7 us, 64->64 39.2 -> 36.3, 128->64 55.5 -> 49.9;
+        // the 16-row tiles of the deep layers are one block per CU either way and lose 20 % with the narrower slice)
+        else if (Cout <= 32 || cot_cap <= 32 || th == 8) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
         else { if (tw == 32) LAUNCH(bf16, 64, 32) else LAUNCH(bf16, 64, 16) }
     } else if (dt == MISEG_F32) {
         if (Cout <= 16) { if (tw == 32) LAUNCH(float, 16, 32) else LAUNCH(float, 16, 16) }
@@ -1462,6 +1480,18 @@ extern "C" int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* i
     BnFinish opt{};
     opt.accumulate_out = 1;
     return conv3x3_fwd_impl(stream, dt, in, Cin, 0, nullptr, 0, 0, N, H, W, packed_w, Cout, inout_pooled, nullptr, opt, true);
+}
+
+// ---- data gradient of a convolution over the channel concat of two full-resolution sources: ONE launch, two destinations
+extern "C" int miseg_conv3x3_dgrad_dual(void* stream, int dt, const void* graw, int64_t K, int64_t N, int64_t H, int64_t W, const void* packed_w,
+                                        int64_t C0, void* out0, int64_t C1, void* out1) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_dgrad_dual, stream, MISEG_BF16, graw, K, N, H, W, packed_w, C0, out0, C1, out1);
+    MISEG_REQUIRE(out0 && out1 && C0 > 0 && C1 > 0 && C0 % 16 == 0 && C1 % 4 == 0, "conv3x3_dgrad_dual: the first source must have a multiple of "
+                  "16 channels, the second a multiple of 4");
+    BnFinish opt{};
+    opt.out1 = out1;
+    opt.split = (int)C0;
+    return conv3x3_fwd_impl(stream, dt, graw, K, 0, nullptr, 0, 0, N, H, W, packed_w, C0 + C1, out0, nullptr, opt);
 }
 
 // ---- data gradient with the BatchNorm backward folded in (unet_ops._ConvBNReLU.backward)

@@ -48,6 +48,7 @@ def join_wgrad_streams() -> None:
 
 
 _FUSE_UPS_DGRAD = True   # False: conv3x3 dgrad + miseg_sumpool2x2 as two launches
+_DUAL_DGRAD = os.environ.get("MISEG_DUAL_DGRAD", "1") != "0"   # concat layers: one data-gradient launch with two destinations
 # BatchNorm backward folded into the convolutions around it (layers without the fused pool): the statistics pass leaves six
 # coefficients per channel, the data- and weight-gradient kernels form graw in their loaders (no bn_bwd_apply pass, no graw tensor),
 # and a data-gradient launch whose output is the activation gradient of ANOTHER such layer takes that layer's statistics pass in its
@@ -325,6 +326,16 @@ class _ConvBNReLU(torch.autograd.Function):
                      _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
                      tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
         grads = [None, None]
+        from .ops import _GradJoin
+        if _DUAL_DGRAD and x1 is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ups0 and not ups1 and \
+                c0 % 16 == 0 and c1 % 4 == 0 and not _GradJoin.enabled and not (_FUSE_BN_BWD and _FUSE_BN_RED):
+            # concat of two full-resolution sources: both data gradients in ONE launch (graw read once, twice the blocks)
+            packed = _pack(weight, dtype, 1, 0, c0 + c1)
+            g0, g1 = empty_nhwc(n, c0, h, w, dtype, dev), empty_nhwc(n, c1, h, w, dtype, dev)
+            call("miseg_conv3x3_dgrad_dual", _stream(), _DT[dtype], _ptr(graw), cout, n, h, w, _ptr(packed), c0, _ptr(g0), c1, _ptr(g1),
+                 work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
+                 tag=f"conv3x3_dgrad[{h}x{w},{cout}->{c0}+{c1}]")
+            return g0, g1, gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
         for s, (cb, cs, ups, xs) in enumerate(((0, c0, ups0, x0), (c0, c1, ups1, x1))):
             if xs is None or not ctx.needs_input_grad[s]:
                 continue

@@ -443,8 +443,39 @@ def test_bn_backward_folded_into_the_convolutions(case, dtype, monkeypatch):
         d_fp = float((a - b).abs().max()) / scale
         assert d_fp <= (3e-2 if dtype == torch.bfloat16 else 4e-3 if half else 2e-5), (case, i, d_fp)
         rel_l2 = float((a - b).norm() / (b.norm() + 1e-20))
-        assert rel_l2 <= (2e-3 if dtype == torch.bfloat16 else 3e-4 if half else 2e-6), (case, i, rel_l2)
+        assert rel_l2 <= (2e-3 if dtype == torch.bfloat16 else 3e-4 if half else 1e-5), (case, i, rel_l2)   # fp32: summation order (measured 4.5e-6)
         # vs the fp32 reference on the same rounded operands: the bounds of _layer_case, as a relative L2 (mask flips are local)
         rel_ref = float((a - r).norm() / (r.norm() + 1e-20))
         # (measured: bf16 <= 0.066 -- the gamma gradients, a cancelling sum --, half <= 0.015, fp32 <= 1.1e-3: a few masks at |y| ~ 1e-7)
         assert rel_ref <= (1e-1 if dtype == torch.bfloat16 else 3e-2 if half else 3e-3), (case, i, rel_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("n,h,w,c0,c1,cout", [(4, 256, 256, 16, 16, 16), (16, 128, 128, 32, 32, 32), (48, 64, 64, 64, 64, 64),
+                                              (48, 32, 32, 128, 128, 128), (6, 250, 230, 16, 8, 16), (3, 20, 36, 32, 12, 16)])
+def test_concat_data_gradient_in_one_launch_equals_the_two_sliced_launches(n, h, w, c0, c1, cout, dtype, monkeypatch):
+    """miseg_conv3x3_dgrad_dual (one launch, two destinations) against the per-source launches: the same products in the same order,
+    so the two gradients must agree bit for bit -- tiled and streaming kernels, ragged tiles, a second source of 8 / 12 channels."""
+    from miseg_amd import unet_ops
+    if dtype == torch.float32 and n * h * w > 48 * 64 * 64:
+        pytest.skip("fp32 runs the tiled kernel; the smaller cases cover it")
+    if dtype != torch.float32 and (c1 % 8 or cout % 8):
+        pytest.skip("16-bit storage needs whole 16-byte channel vectors")
+    outs = []
+    for dual in (True, False):
+        monkeypatch.setattr(unet_ops, "_DUAL_DGRAD", dual)
+        names = []
+        real = unet_ops.call
+        monkeypatch.setattr(unet_ops, "call", lambda name, *a, **k: (names.append(name), real(name, *a, **k))[1])
+        x0 = nhwc(T(synth.normal("dual/x0", (n, c0, h, w))).to(DEV).to(dtype)).requires_grad_(True)
+        x1 = nhwc(T(synth.normal("dual/x1", (n, c1, h, w))).to(DEV).to(dtype)).requires_grad_(True)
+        wt = T(synth.normal("dual/w", (cout, c0 + c1, 3, 3), scale=(2.0 / ((c0 + c1) * 9)) ** 0.5)).to(DEV).requires_grad_(True)
+        bn = make_bn(cout, "dual/bn")
+        y, _ = unet_ops.conv_bn_relu(x0, x1, wt, bn["weight"].to(DEV).requires_grad_(True), bn["bias"].to(DEV).requires_grad_(True),
+                                     bn["running_mean"].to(DEV), bn["running_var"].to(DEV), bn["nbt"].to(DEV), True, 0, 0, False)
+        (y.float() * T(synth.normal("dual/cot", tuple(y.shape))).to(DEV)).sum().backward()
+        monkeypatch.setattr(unet_ops, "call", real)
+        assert ("miseg_conv3x3_dgrad_dual" in names) == dual
+        outs.append((x0.grad.clone(), x1.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].float().abs().max()) > 0 and float(outs[0][1].float().abs().max()) > 0
