@@ -46,6 +46,10 @@ extern "C" {
 
 int miseg_version(void);
 const char* miseg_last_error(void);
+/* Make stream `waiter` wait for the work enqueued on stream `producer` so far (both hipStream_t of this device, passed as void*): the
+ * cross-stream ordering the host side needs around its side streams (weight gradients, IIC branch; the reference is single-stream, the
+ * PyTorch call this replaces is torch.cuda.Stream.wait_stream).  Uses device-scope-release events (no system fence). */
+int miseg_stream_wait_stream(void* waiter, void* producer);
 
 /* ------------------------------------------------------------------------------------------
  * Local (displacement-window) IIC mutual information

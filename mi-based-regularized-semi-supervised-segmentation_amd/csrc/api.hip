@@ -17,3 +17,38 @@ int fail(int code, const char* fmt, ...) {
 
 extern "C" int miseg_version(void) { return 301; }   // round 3 (profiles/r03_*.json are keyed by this)
 extern "C" const char* miseg_last_error(void) { return miseg::last_error_buf(); }
+
+// ---- cross-stream ordering without a system-scope fence --------------------------------------------------------------------------
+// `waiter` waits for everything enqueued on `producer` so far (torch's stream.wait_stream(other)), through a pooled event created with
+// hipEventDisableTiming | hipEventDisableSystemFence: the recorded marker then releases at device scope only.  A torch event releases
+// to SYSTEM scope -- cache writeback + invalidation across the whole device -- which showed as a ~7 us bubble in front of the next
+// kernel of the producing stream at every weight-gradient fork of the backward pass (22 per step; profiles/r03*_critical_path.txt).
+// Both streams belong to this process and this device; nothing on the host reads what the producer wrote through this ordering.
+namespace miseg_core {
+static hipEvent_t next_fork_event() {
+    constexpr int kRing = 256;                        // an event may be re-recorded while earlier waits on it are still queued
+    static thread_local hipEvent_t ring[kRing];
+    static thread_local int made = 0, next = 0;
+    static const unsigned flags = [] {
+        const char* e = getenv("MISEG_FORK_EVENT_FLAGS");
+        return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+    }();
+    if (made < kRing) {
+        if (hipEventCreateWithFlags(&ring[made], flags) != hipSuccess) return nullptr;
+        ++made;
+    }
+    hipEvent_t ev = ring[next % made];
+    next = (next + 1) % kRing;
+    return ev;
+}
+}  // namespace miseg_core
+
+extern "C" int miseg_stream_wait_stream(void* waiter, void* producer) {
+    if (waiter == producer) return MISEG_OK;
+    hipEvent_t ev = miseg_core::next_fork_event();
+    if (!ev) return miseg_core::fail(MISEG_E_LAUNCH, "stream_wait_stream: hipEventCreateWithFlags failed");
+    hipError_t e = hipEventRecord(ev, reinterpret_cast<hipStream_t>(producer));
+    if (e == hipSuccess) e = hipStreamWaitEvent(reinterpret_cast<hipStream_t>(waiter), ev, 0);
+    if (e != hipSuccess) return miseg_core::fail(MISEG_E_LAUNCH, "stream_wait_stream: %s", hipGetErrorString(e));
+    return MISEG_OK;
+}

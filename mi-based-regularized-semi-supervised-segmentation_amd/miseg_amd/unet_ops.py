@@ -19,7 +19,7 @@ from torch import Tensor
 
 from ._cabi import call, query
 from .gradslot import grad_slot
-from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc
+from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc, wait_stream
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
@@ -43,7 +43,7 @@ def wgrad_stream(device):
 def join_wgrad_streams() -> None:
     """Make the current stream wait for every outstanding side-stream wgrad."""
     for dev in list(_wgrad_dirty):
-        torch.cuda.current_stream(dev).wait_stream(_wgrad_streams[dev])
+        wait_stream(torch.cuda.current_stream(dev), _wgrad_streams[dev])
     _wgrad_dirty.clear()
 
 
@@ -315,7 +315,7 @@ class _ConvBNReLU(torch.autograd.Function):
                     # param.grad (which already aliases the flat slot) is safe to touch from the main stream as soon as
                     # backward() returns -- gradient accumulation, clip_grad_norm_, inspection -- not only after collect()
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
-                side.wait_stream(cur)         # graw is produced above
+                wait_stream(side, cur)        # graw is produced above
                 for t in (graw, x0, x1):      # keep their memory from being recycled under the side stream
                     if t is not None:
                         t.record_stream(side)
@@ -421,7 +421,7 @@ class _ConvBNReLU(torch.autograd.Function):
             if side is not None:
                 if not _wgrad_dirty:
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
-                side.wait_stream(cur)         # coef is produced above
+                wait_stream(side, cur)        # coef is produced above
                 for t in (raw, gy, coef, x0, x1):
                     if t is not None:
                         t.record_stream(side)

@@ -537,7 +537,7 @@ class IICTrainEpocher(TrainEpocher):
         idx = self._feature_position.index(name)
         projector, criterion = list(self._projectors_wrapper)[idx], list(self._IIDSegCriterionWrapper)[idx]
         main, side = torch.cuda.current_stream(feature.device), self._side(feature.device)
-        side.wait_stream(main)
+        ops.wait_stream(side, main)
         feature.record_stream(side)
         with torch.cuda.stream(side):
             self._early[name] = self._tap_loss(feature, projector, criterion, self._flips2, self._ub_now)
@@ -546,10 +546,10 @@ class IICTrainEpocher(TrainEpocher):
         if not self._use_side_stream(flips.device):
             return self._iic_body(flips, ub)
         main, side = torch.cuda.current_stream(flips.device), self._side(flips.device)
-        side.wait_stream(main)
+        ops.wait_stream(side, main)
         with torch.cuda.stream(side):
             out = self._iic_body(flips, ub)
-        main.wait_stream(side)
+        ops.wait_stream(main, side)
         for t, _ in LinearLoss.of(out).terms:      # produced on `side`, read on `main`: keep the allocator informed
             t.record_stream(main)
         return out
