@@ -59,12 +59,16 @@ __device__ __forceinline__ void zero_vec(T* dst) {
 // BNL: the (single, full-resolution) source is a BatchNorm layer's raw output and bl.gy the gradient of its activation -- the loader
 // forms graw (common.h, bn_graw_vec); out-of-image halo pixels stay zero.  RED: the epilogue also takes the BatchNorm-backward sums of
 // the layer that produced this launch's output tensor (BnRed; non-pooled output, Cout % 4 == 0, no forward statistics).
-template <typename T, int COT, int TW, int THT, bool POOL = false, bool BNL = false, bool RED = false>
-__global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
+// NW waves per block (4, or 8 for the 16-row tiles of the deep layers: the same LDS tile -- one block per CU either way -- worked by two
+// waves per SIMD that cover each other's LDS round trips, each with half the rows).
+template <typename T, int COT, int TW, int THT, bool POOL = false, bool BNL = false, bool RED = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
                                                         T* __restrict__ out, float* __restrict__ stats, BnFinish fin, BnLoad bl, BnRed br) {
     static_assert(!(RED && POOL), "the epilogue reduce exists for full-resolution outputs");
     typedef Mma<T> MM;
-    constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, RW = THT / 4, MTW = RW * MTR;   // RW rows of the tile per wave
+    constexpr int kCT = 64 * NW;                            // shadows the file-scope block size inside this kernel
+    static_assert(THT % NW == 0, "whole rows per wave");
+    constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, RW = THT / NW, MTW = RW * MTR;   // RW rows of the tile per wave
     constexpr int KP = MM::KP;                              // LDS stride of one pixel / one weight row (elements)
     constexpr int IW = TW + 2, IH = THT + 2;
     constexpr int NIS = (IH * IW * (CK / VEC) + kCT - 1) / kCT, NWS = (9 * COT * (CK / VEC) + kCT - 1) / kCT;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
     }
     if (RED) stats = br.parts;
     if (stats) {
-        __shared__ float sred[4][2][COT];
+        __shared__ float sred[NW][2][COT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -319,6 +323,8 @@ __global__ __launch_bounds__(kCT, 1) void conv3x3_kernel(ConvSrc src, int N, int
         if (tid < COT && co0 + tid < Cout) {
             float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
             float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+#pragma unroll
+            for (int q = 4; q < NW; ++q) { a += sred[q][0][tid]; b += sred[q][1][tid]; }
             if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
             store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
             store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
@@ -1348,14 +1354,19 @@ template <typename TT, int COT, int TWW, int THH, bool POOL>
 static void launch_tiled(dim3 grid, hipStream_t st, const ConvSrc& s, int N, int H, int W, const void* wpk, int Cout, void* out, float* stats,
                          const BnFinish& fin, const BnLoad& bl, const BnRed& br) {
     const size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);
-#define GO(BNL, RED)                                                                                                                 \
+#define GO(BNL, RED, NWW)                                                                                                            \
     {                                                                                                                               \
-        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
-        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED>), grid, dim3(kCT), lb, st, s, N, H, W, (const TT*)wpk, Cout,  \
-                           (TT*)out, stats, fin, bl, br);                                                                           \
+        hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \
+        hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED, NWW>), grid, dim3(64 * NWW), lb, st, s, N, H, W, (const TT*)wpk, \
+                           Cout, (TT*)out, stats, fin, bl, br);                                                                     \
     }
-    if constexpr (POOL) { if (bl.gy) GO(true, false) else GO(false, false) }
-    else { if (bl.gy && br.raw) GO(true, true) else if (bl.gy) GO(true, false) else if (br.raw) GO(false, true) else GO(false, false) }
+    // 16-row tiles of 16-bit layers: 8 waves (plain forms; the fused forms keep 4)
+    static const int nw_knob = [] { const char* e = getenv("MISEG_CONV_NW"); return e ? atoi(e) : 8; }();
+    if constexpr (THH == 16 && sizeof(TT) == 2) {
+        if (nw_knob == 8 && !bl.gy && !br.raw) { GO(false, false, 8) return; }
+    }
+    if constexpr (POOL) { if (bl.gy) GO(true, false, 4) else GO(false, false, 4) }
+    else { if (bl.gy && br.raw) GO(true, true, 4) else if (bl.gy) GO(true, false, 4) else if (br.raw) GO(false, true, 4) else GO(false, false, 4) }
 #undef GO
 }
 // rows per wave of the streaming kernel's fused forms (see the kernel): 2 unless 16 gradient channels meet 16 outputs or a pooled output
