@@ -26,19 +26,19 @@ extern "C" const char* miseg_last_error(void) { return miseg::last_error_buf(); 
 // Both streams belong to this process and this device; nothing on the host reads what the producer wrote through this ordering.
 namespace miseg_core {
 static hipEvent_t next_fork_event() {
-    constexpr int kRing = 256;                        // an event may be re-recorded while earlier waits on it are still queued
-    static thread_local hipEvent_t ring[kRing];
-    static thread_local int made = 0, next = 0;
-    static const unsigned flags = [] {
-        const char* e = getenv("MISEG_FORK_EVENT_FLAGS");
-        return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
-    }();
-    if (made < kRing) {
-        if (hipEventCreateWithFlags(&ring[made], flags) != hipSuccess) return nullptr;
-        ++made;
+    constexpr int kRing = 256, kDev = 16;            // an event may be re-recorded while earlier waits on it are still queued
+    struct Ring { hipEvent_t ev[kRing]; int made = 0, next = 0; };
+    static thread_local Ring rings[kDev];             // events belong to the device that was current when they were created
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDev) return nullptr;
+    Ring& r = rings[dev];
+    constexpr unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
+    if (r.made < kRing) {
+        if (hipEventCreateWithFlags(&r.ev[r.made], flags) != hipSuccess) return nullptr;
+        ++r.made;
     }
-    hipEvent_t ev = ring[next % made];
-    next = (next + 1) % kRing;
+    hipEvent_t ev = r.ev[r.next % r.made];
+    r.next = (r.next + 1) % kRing;
     return ev;
 }
 }  // namespace miseg_core

@@ -1329,9 +1329,7 @@ static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
 // tile height of the generic kernel (bf16): 8 rows from 64^2 upwards (smaller LDS tile -> two blocks per CU; measured
 // 128^2 64->32: 78 -> 64 us), 16 rows for the small deep layers (32^2: 8-row tiles cost 46 -> 55 us) and for exact fp32
 static int generic_tile_h(int dt, int64_t H, int64_t W) {
-    static const int force = [] { const char* e = getenv("MISEG_CONV_TH"); return e ? atoi(e) : 0; }();   // scratch sweeps
     if (dt != MISEG_BF16) return 16;
-    if (force == 8 || force == 16) return force;
     return H * W >= 64 * 64 ? 8 : 16;
 }
 
@@ -1360,10 +1358,10 @@ static void launch_tiled(dim3 grid, hipStream_t st, const ConvSrc& s, int N, int
         hipLaunchKernelGGL((conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED, NWW>), grid, dim3(64 * NWW), lb, st, s, N, H, W, (const TT*)wpk, \
                            Cout, (TT*)out, stats, fin, bl, br);                                                                     \
     }
-    // 16-row tiles of 16-bit layers: 8 waves (plain forms; the fused forms keep 4)
-    static const int nw_knob = [] { const char* e = getenv("MISEG_CONV_NW"); return e ? atoi(e) : 8; }();
+    // 16-row tiles of 16-bit layers: 8 waves (plain forms; the fused forms keep 4).  Same box, forward, us: 32^2 64->128 21.3 -> 20.6,
+    // 128->128 29.4 -> 26.5, 256->128 45.4 -> 41.9; 16^2 128->256 19.0 -> 17.8, 256->256 27.4 -> 26.3 (gpurun_out/sweep_nw.log)
     if constexpr (THH == 16 && sizeof(TT) == 2) {
-        if (nw_knob == 8 && !bl.gy && !br.raw) { GO(false, false, 8) return; }
+        if (!bl.gy && !br.raw) { GO(false, false, 8) return; }
     }
     if constexpr (POOL) { if (bl.gy) GO(true, false, 4) else GO(false, false, 4) }
     else { if (bl.gy && br.raw) GO(true, true, 4) else if (bl.gy) GO(true, false, 4) else if (br.raw) GO(false, true, 4) else GO(false, false, 4) }
@@ -1447,12 +1445,11 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
         else { if (th == 8) LAUNCH_P(16, 8) else LAUNCH_P(16, 16) }
 #undef LAUNCH_P
     } else if (dt == MISEG_BF16) {
-        static const int cot_cap = [] { const char* e = getenv("MISEG_CONV_COT"); return e ? atoi(e) : 64; }();   // scratch sweeps
         if (Cout <= 16) { if (tw == 32) LAUNCH(bf16, 16, 32) else LAUNCH(bf16, 16, 16) }
         // 8-row tiles (maps from 64^2 up) take 32 output channels per block: with 64 the weight chunk makes the block's LDS 88 KB -- one
         // block per CU --, with 32 it is 60 KB and two fit (64^2, same box: 32->64 31.8 -> 26.7 us, 64->64 39.2 -> 36.3, 128->64 55.5 -> 49.9;
         // the 16-row tiles of the deep layers are one block per CU either way and lose 20 % with the narrower slice)
-        else if (Cout <= 32 || cot_cap <= 32 || th == 8) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
+        else if (Cout <= 32 || th == 8) { if (tw == 32) LAUNCH(bf16, 32, 32) else LAUNCH(bf16, 32, 16) }
         else { if (tw == 32) LAUNCH(bf16, 64, 32) else LAUNCH(bf16, 64, 16) }
     } else if (dt == MISEG_F32) {
         if (Cout <= 16) { if (tw == 32) LAUNCH(float, 16, 32) else LAUNCH(float, 16, 16) }

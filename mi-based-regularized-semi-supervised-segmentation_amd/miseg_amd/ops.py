@@ -41,7 +41,7 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-_LIB_FORK = os.environ.get("MISEG_LIB_FORK", "1") != "0"
+_LIB_FORK = True         # False: torch.cuda.Stream.wait_stream (system-scope events)
 
 
 def wait_stream(waiter: "torch.cuda.Stream", producer: "torch.cuda.Stream") -> None:

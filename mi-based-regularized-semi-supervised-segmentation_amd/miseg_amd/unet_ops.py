@@ -48,13 +48,13 @@ def join_wgrad_streams() -> None:
 
 
 _FUSE_UPS_DGRAD = True   # False: conv3x3 dgrad + miseg_sumpool2x2 as two launches
-_DUAL_DGRAD = os.environ.get("MISEG_DUAL_DGRAD", "1") != "0"   # concat layers: one data-gradient launch with two destinations
+_DUAL_DGRAD = True       # concat layers: one data-gradient launch with two destinations (False: one launch per source)
 # BatchNorm backward folded into the convolutions around it (layers without the fused pool): the statistics pass leaves six
 # coefficients per channel, the data- and weight-gradient kernels form graw in their loaders (no bn_bwd_apply pass, no graw tensor),
 # and a data-gradient launch whose output is the activation gradient of ANOTHER such layer takes that layer's statistics pass in its
-# epilogue (no bn_relu_bwd_reduce pass there).  MISEG_BN_FUSE=0: the three-pass form everywhere.
+# epilogue (no bn_relu_bwd_reduce pass there).  OFF by default (MISEG_BN_FUSE=1 turns it on): measured slower, DESIGN.md section 9.
 _FUSE_BN_BWD = os.environ.get("MISEG_BN_FUSE", "0") == "1"
-_FUSE_BN_RED = os.environ.get("MISEG_BN_FUSE_RED", "1") != "0"
+_FUSE_BN_RED = True      # ... including the statistics pass in the producing data-gradient kernel's epilogue
 
 
 class _BnRec:
