@@ -486,7 +486,9 @@ def _red_target(src_rec: Optional[_BnRec], ups: int, dtype, cout: int, n: int, h
 def conv_bn_relu(x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor,
                  running_var: Tensor, nbt: Tensor, training: bool, ups0: int = 0, ups1: int = 0,
                  want_pool: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-    rec = None if want_pool else _BnRec()      # a pooled layer's backward routes through the 2x2 windows: it keeps its own reduce
+    # the hand-over record exists only where it can be used: the opt-in fused backward, a layer without the fused pool (a pooled layer's
+    # backward routes through the 2x2 windows and keeps its own reduce), a forward pass that records a graph
+    rec = _BnRec() if (_FUSE_BN_BWD and _FUSE_BN_RED and not want_pool and torch.is_grad_enabled()) else None
     rec0 = getattr(x0, "_miseg_bn", None) if not ups0 else None
     rec1 = getattr(x1, "_miseg_bn", None) if x1 is not None and not ups1 else None
     y, pooled = _ConvBNReLU.apply(x0, x1, weight, gamma, beta, running_mean, running_var, nbt, bool(training), int(ups0), int(ups1),
