@@ -479,3 +479,16 @@ def test_concat_data_gradient_in_one_launch_equals_the_two_sliced_launches(n, h,
         outs.append((x0.grad.clone(), x1.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][0].float().abs().max()) > 0 and float(outs[0][1].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(48, 1, 256, 256), (3, 1, 50, 46), (2, 3, 20, 36)])
+def test_stem_input_is_the_cast_image_padded_with_zero_channels(shape, dtype):
+    """miseg_cast_pad (both kernels: the one-channel 16-byte-vector form the bench runs, and the generic one) bit for bit."""
+    from miseg_amd import unet_ops
+    img = T(synth.normal("stem_input/img", shape)).to(DEV)
+    out = unet_ops.stem_input(img, dtype)
+    vec = unet_ops.vec_of(dtype)
+    cp = (shape[1] + vec - 1) // vec * vec
+    assert tuple(out.shape) == (shape[0], cp, shape[2], shape[3]) and out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out[:, :shape[1]], img.to(dtype)) and float(out[:, shape[1]:].float().abs().max()) == 0.0
