@@ -75,8 +75,13 @@ class GradReducer:
         self._armed = False
         self.timing = False                 # bench.py: record an event pair around finish()'s waits
         self._wait_events: list = []
-        for i, p in enumerate(flat.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        # Gradient hooks.  The first armed backward pass runs one Python hook per parameter (~125) and learns which parameter of each
+        # bucket gets its gradient LAST; from then on only those trigger parameters keep a hook (one per bucket instead of ~40: the hooks
+        # alone cost a one-rank run 0.2-0.3 ms of host time per step on the thread that issues the backward launches).  A trigger that
+        # fires while another parameter of its bucket has no gradient yet (the order changed) launches nothing; finish() flushes.
+        self._last_in_bucket: List[Optional[int]] = [None] * len(self.buckets)
+        self._triggers_only = False
+        self._hook_handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
         if broadcast_params:
             dist.broadcast(flat.flat_param, src=0, group=process_group)
 
@@ -85,24 +90,50 @@ class GradReducer:
             if not self._armed:
                 return
             b = self._bucket_of[index]
+            if self._triggers_only:
+                lo, hi, _, _ = self.buckets[b]
+                if self._handles[b] is None and all(p.grad is not None for p in self.flat.params[lo:hi]):
+                    self._launch(b)
+                return
+            self._last_in_bucket[b] = index
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
         return hook
 
+    def _keep_trigger_hooks(self) -> None:
+        keep = set(i for i in self._last_in_bucket if i is not None)
+        if len(keep) != len(self.buckets):
+            return                  # some bucket saw no gradient at all in the learning pass: keep every hook
+        for i, h in enumerate(self._hook_handles):
+            if i not in keep:
+                h.remove()
+        self._triggers_only = True
+
     def _launch(self, b: int) -> None:
         lo, hi, start, end = self.buckets[b]
-        if self.producer_streams and self.flat.flat_grad.is_cuda:
-            # a bucket mixes gradients written on different HIP streams (the IIC branch has its own): the stream that
-            # launches the collective must see all of them
-            cur = torch.cuda.current_stream(self.flat.flat_grad.device)
-            for s in self.producer_streams:
-                if s != cur:
-                    cur.wait_stream(s)
-        self.flat.collect(lo, hi)   # gradients that autograd parked elsewhere (or that never arrived) -> flat slice
-        view = self.flat.flat_grad[start:end]
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
-        self._handles[b] = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+        if not self.flat.flat_grad.is_cuda:
+            self.flat.collect(lo, hi)
+            self._handles[b] = dist.all_reduce(self.flat.flat_grad[start:end], op=op, group=self.group, async_op=True)
+            return
+        # A bucket mixes gradients written on different HIP streams: the stream this hook runs on (BatchNorm / head parameters), the
+        # weight-gradient stream, the IIC branch.  The collective is launched from the WEIGHT-GRADIENT stream, made to wait for the
+        # others: the backward pass's own stream never waits for the weight gradients to drain in the middle of the pass, and no further
+        # stream is created -- with RCCL's own that makes four, the number of hardware queues a process gets by default
+        # (GPU_MAX_HW_QUEUES); a fifth stream shares a queue with one of the others and the step time became bimodal (6.95 / 7.4 ms).
+        from . import ops, unet_ops
+        dev = self.flat.flat_grad.device
+        cur = torch.cuda.current_stream(dev)
+        rs = unet_ops.wgrad_stream(dev)
+        for s in [cur] + [s for s in self.producer_streams if s != cur and s != rs]:
+            ops.wait_stream(rs, s)
+        torch.cuda.set_stream(rs)       # (not the `with torch.cuda.stream` context: 15-20 us of host time per use)
+        try:
+            self.flat.collect(lo, hi)   # joins the weight-gradient stream into rs; gradients autograd parked elsewhere -> flat slice
+            self._handles[b] = dist.all_reduce(self.flat.flat_grad[start:end], op=op, group=self.group, async_op=True)
+        finally:
+            torch.cuda.set_stream(cur)
 
     def prepare(self) -> None:
         """Call after zero_grad(), before backward()."""
@@ -114,8 +145,10 @@ class GradReducer:
     def finish(self) -> None:
         """Call after backward(), before optimizer.step(): flush unlaunched buckets, wait, average."""
         self._armed = False
+        if not self._triggers_only:
+            self._keep_trigger_hooks()
         for b in range(len(self.buckets)):
-            if self._handles[b] is None:  # some parameter of the bucket got no gradient this step
+            if self._handles[b] is None:  # some parameter of the bucket got no gradient this step (or its trigger fired early)
                 self._launch(b)
         timed = self.timing and self.flat.flat_grad.is_cuda
         if timed:       # from "this stream has nothing left but to wait for the collectives" to "they are done": the EXPOSED part

@@ -123,6 +123,8 @@ class FlatBuffers:
                         torch.mul(g, 1.0, out=slot)    # a kernel, not hipMemcpyDtoD (which can stall for 100s of us on a busy device)
                     else:
                         slot.copy_(g)
+                    if g.is_cuda:
+                        g.record_stream(torch.cuda.current_stream(g.device))   # may be another stream than g's own (GradReducer._launch)
                 else:
                     continue
                 p.grad = slot

@@ -320,11 +320,24 @@ class _ConvBNReLU(torch.autograd.Function):
                     if t is not None:
                         t.record_stream(side)
                 _wgrad_dirty.add(dev)
-            with torch.cuda.stream(side if side is not None else cur):
-                ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
-                call("miseg_conv3x3_wgrad", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
+            # launched on the side stream by HANDLE (entering the `torch.cuda.stream` context costs 15-20 us of host time, 22 times per
+            # backward pass); the workspace comes from the current stream's pool and is handed to the side stream like the operands
+            ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
+            if side is not None:
+                ws2.record_stream(side)
+
+            def launch(stream_handle):
+                call("miseg_conv3x3_wgrad", stream_handle, _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
                      _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
                      tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
+            from . import _cabi
+            if side is None:
+                launch(_stream())
+            elif _cabi.TIMER is not None:       # the per-kernel timer records its events on torch's current stream
+                with torch.cuda.stream(side):
+                    launch(_stream())
+            else:
+                launch(side.cuda_stream)
         grads = [None, None]
         from .ops import _GradJoin
         if _DUAL_DGRAD and x1 is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ups0 and not ups1 and \
