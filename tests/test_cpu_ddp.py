@@ -40,11 +40,28 @@ def _worker(rank, world, port, out_dir):
     assert len(red.buckets) >= 2 and red.buckets[0][3] == flat.total and red.buckets[-1][2] == 0
     g = torch.Generator().manual_seed(100 + rank)
     x, y = torch.randn(5, 6, generator=g), torch.randn(5, 3, generator=g)
-    for _ in range(2):  # two steps: state resets correctly
+    for it in range(3):  # state resets correctly; from the second pass on only the learned trigger hooks are left
         flat.zero_grad()
         red.prepare()
         _loss(model, x, y).backward()
         red.finish()
+        assert red._triggers_only and sum(1 for i in red._last_in_bucket if i is not None) == len(red.buckets)
+    # a pass in which the gradients arrive in ANOTHER order (the last layer's output is not used: its bucket's trigger never fires,
+    # an earlier bucket's trigger fires while ... ) must still reduce everything: finish() flushes what the triggers left
+    flat.zero_grad()
+    red.prepare()
+    h = model[2](model[1](model[0](x)))
+    (h ** 2).mean().backward()
+    red.finish()
+    partial = flat.flat_grad.clone()
+    ref_partial = [torch.zeros_like(partial) for _ in range(world)]
+    dist.all_gather(ref_partial, partial)
+    assert all(torch.equal(ref_partial[0], t) for t in ref_partial)        # every rank holds the same (averaged) gradient
+    assert float(partial.abs().max()) > 0
+    flat.zero_grad()
+    red.prepare()
+    _loss(model, x, y).backward()
+    red.finish()
     torch.save({"grad": flat.flat_grad.clone(), "param": flat.flat_param.clone()}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
