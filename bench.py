@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"],
                     help="storage / MFMA operand type of the U-Net and head kernels (float16 = BASELINE configs[4]'s arithmetic: IEEE half, "
-                         "static loss scale MISEG_LOSS_SCALE, default 2^14)")
+                         "dynamic loss scale starting at MISEG_LOSS_SCALE, default 2^14)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4"],
                     help="BASELINE.json configs[1] (default: 4 classes, 256^2, whole-map local MI) or configs[3] (8 classes, 512^2, local MI over "
                          "the 7 x 7 grid of overlapping 128^2 patches, +-3 displacement on Up_conv2; --lb / --ub / --size still apply on top)")
@@ -304,10 +304,10 @@ def main():
                          "where a kernel has that form, the bf16 hi/lo split elsewhere -- and fp32 with --dtype float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the device half of the step as one captured hipGraph (miseg_amd.graph); at the cfg2 shape the step is "
-                         "GPU-bound either way (13.6 ms replayed vs 13.5 ms eager), so eager -- with per-kernel events inside the "
-                         "timed region -- stays the default")
+    ap.add_argument("--eager", action="store_true",
+                    help="issue every iteration from Python (two threads, ~300 ctypes calls); default on one GPU: after three eager "
+                         "iterations the library records its own calls during one more and replays that launch tape from one C call "
+                         "per iteration (miseg_amd.tape) -- same launches, same streams, same results, ~1 ms of host time")
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "acdc", "host"],
                     help="synthetic = resident ACDC-shaped tensors (BASELINE metric, default); acdc = batches drawn every step by the "
                          "device input pipeline from an ACDC-format PNG set (224^2 crops, as the reference trains)")
@@ -363,13 +363,15 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"built step: world={world} LB=UB={args.lb} {args.size}x{args.size} {args.dtype}")
-    # Per-kernel HIP-event timing costs host time (two events per call) and cannot be recorded inside a replayed hipGraph,
-    # so the full table is taken over the last EAGER warm-up steps; inside the timed region only the dominant kernel is
-    # timed (eager runs) -- with the step graph on (default on one GPU) the warm-up figure of that kernel feeds `roofline`.
-    use_graph = world == 1 and args.graph and hasattr(ep, "enable_step_graph")
-    eager_warm = max(1, args.warmup - 2) if use_graph else args.warmup
-    if use_graph:
-        ep.enable_step_graph(warmup=eager_warm)
+    # The launch tape (default on one GPU; data-parallel runs stay eager): iterations 0-2 run eagerly, iteration 3 eagerly while the
+    # library records its calls, everything after is replayed.  Per-kernel HIP-event timing of EVERY entry point costs host time (two
+    # events per call), so the full table is taken over eager warm-up iterations; inside the timed region only the dominant kernel is
+    # timed, live, on the stream it is launched on: by the tape itself when it replays (miseg_tape_time_op), by the ctypes wrapper
+    # when the run is eager.
+    use_tape = world == 1 and not distributed and not args.eager
+    if not use_tape:
+        ep._TAPE_DEFAULT = False
+    eager_warm = min(3, args.warmup) if use_tape else args.warmup
     survey, timer = None, None
     use_timer = rank == 0 and not args.no_kernel_timer
     survey_steps = min(2, eager_warm) if use_timer else 0
@@ -381,17 +383,18 @@ def main():
         if i == eager_warm:
             _cabi.TIMER = None
         drv.step()
-        note(f"warmup step {i} done" + (" (graph)" if use_graph and i >= eager_warm else ""))
+        tp = ep._step_tape
+        note(f"warmup step {i} done" + (" (launch tape)" if tp is not None and tp.replays else ""))
     _cabi.TIMER = None
     table = []
+    timed_ops = []
     if survey is not None and survey.records:
         torch.cuda.synchronize()
         # ranked by calls x SHORTEST duration: an event pair around a kernel of a side stream also counts the time the kernel waited for
         # compute units held by another stream's kernel (a 50 us head forward read 2 ms once) -- the shortest call did not wait
         table = sorted(survey.summary().items(), key=lambda kv: -kv[1]["min_ms"] * kv[1]["calls"])
-        if not use_graph:
-            timer = _cabi.KernelTimer(only={table[0][0]})
-            _cabi.TIMER = timer
+        timer = _cabi.KernelTimer(only={table[0][0]})      # eager iterations of the timed region (all of them with --eager)
+        _cabi.TIMER = timer
     if distributed and getattr(ep, "_reducer", None) is not None:
         ep._reducer.timing = True
         ep._reducer._wait_events = []
@@ -408,6 +411,9 @@ def main():
         return out
     _Pending.wait = staticmethod(timed_wait)
     barrier()
+    tape = ep._step_tape
+    if tape is not None and tape.handle and table:
+        timed_ops = tape.time_tag(table[0][0])             # the recorded iteration's launches of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
@@ -453,19 +459,26 @@ def main():
                                     f"Up_conv2, K=20 x 5 sub-heads, paddings [1,3], local MI over overlapping 128x128 patches (stride 64: "
                                     f"{(args.size // 64 - 1) ** 2} windows on Up_conv2) (BASELINE configs[3])"),
                        "mi_precision": mi_prec, "global_batch": (args.lb + args.ub) * world, "forward_images_per_step": (args.lb + 2 * args.ub) * world,
-                       "parallelism": f"dp{world}", "step_graph": bool(use_graph)},
+                       "parallelism": f"dp{world}",
+                       "launch_tape": bool(tape is not None and tape.replays), "tape_ops": (tape.n_ops if tape is not None and tape.handle else None),
+                       "tape_replays_in_run": (tape.replays if tape is not None else 0),
+                       "tape_refused": (tape.disabled if tape is not None else None)},
             # what the collective library actually saw (1 / null when this is a single process without torch.distributed)
             "rccl_ranks": torch.distributed.get_world_size() if distributed else 1,
             "backend": torch.distributed.get_backend() if distributed else None,
             "per_rank": per_rank,
         }
         if table:
+            name, top = table[0]
+            ms = [v for op in timed_ops for v in tape.timed_ms(op)] if timed_ops else []
             if timer is not None and timer.records:
-                name, top = next(iter(timer.summary().items()))
-                calls_per_step, timed_in = top["calls"] / args.steps, "timed region (eager)"
-            else:   # graph replay: per-kernel events are not recordable inside the graph -> eager warm-up steps of this process
-                name, top = table[0]
-                calls_per_step, timed_in = top["calls"] / survey_steps, "eager warm-up steps (timed region replays a hipGraph)"
+                ms += [s.elapsed_time(e) for s, e, _, _ in timer.records[name]]
+            if ms:      # live, inside the timed region: HIP events around the kernel on its own stream (tape replays + any eager iterations)
+                top = dict(top, avg_ms=sum(ms) / len(ms), min_ms=min(ms), calls=len(ms))
+                calls_per_step = len(ms) / args.steps
+                timed_in = "timed region (" + ("launch tape replays" if timed_ops else "eager") + ")"
+            else:
+                calls_per_step, timed_in = top["calls"] / survey_steps, "eager warm-up steps"
             # which matrix pipe the kernel runs on: local-MI follows --mi-precision (bf16x3 = three bf16 MFMAs per
             # algorithmic product, priced against the plain bf16 dense peak), head backward is fp32 MFMA, convs follow --dtype
             mfma_f32 = name.startswith("head_local_bwd") or (name.startswith("iic_local") and mi_prec == "fp32") or \

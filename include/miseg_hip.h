@@ -52,6 +52,58 @@ const char* miseg_last_error(void);
 int miseg_stream_wait_stream(void* waiter, void* producer);
 
 /* ------------------------------------------------------------------------------------------
+ * Launch tape: one iteration of the reference's hot loop (ref: semi_seg/epocher.py:143-187) issued from ONE C call.
+ * The reference drives its step from Python, and so does this repo: ~300 launches on three streams from two Python threads
+ * (caller + autograd engine).  With fixed shapes that list of (entry point, arguments, stream) is the same every iteration, so
+ * the library records its own entry-point calls once -- every `int miseg_*(void* stream, ...)` below appends itself while a tape
+ * is being recorded, whichever thread calls it -- and miseg_tape_replay calls them again in the recorded order: per-stream order
+ * and cross-stream waits are exactly those of the recorded (eager) iteration, the host spends a few microseconds per launch.
+ *   tape  = miseg_tape_begin()                 start recording (0 if another tape is being recorded); the calls still execute
+ *   seg   = miseg_tape_mark(tape)              segment boundary: the host does something between segments (an RCCL all-reduce)
+ *   miseg_tape_end(tape)
+ *   slot  = miseg_tape_bind(tape, base, span)  every recorded POINTER argument p in [base, base + span) is re-based at replay:
+ *                                              p' = values[slot] + (p - base).  Bound are the loader's batch tensors, the pinned
+ *                                              staging slots of miseg_upload / miseg_download, the event of miseg_event_record.
+ *   miseg_tape_replay(tape, segment, values, nvalues)      nvalues = number of bindings; they are applied at segment 0
+ *   miseg_tape_time_op / miseg_tape_timed_ms   HIP-event pair around one op at every replay, on the op's own stream
+ * Everything else the recorded calls point at must stay where it is (the host keeps the recorded iteration's allocations in
+ * a private pool).  Entry points that read HOST arrays during the call (miseg_flip's strides) record their own copy of them.
+ * ------------------------------------------------------------------------------------------ */
+int64_t miseg_tape_begin(void);
+int miseg_tape_end(int64_t tape);
+int miseg_tape_free(int64_t tape);
+int64_t miseg_tape_mark(int64_t tape);
+int64_t miseg_tape_len(int64_t tape);
+int64_t miseg_tape_segments(int64_t tape);
+const char* miseg_tape_op_name(int64_t tape, int64_t op);
+int64_t miseg_tape_op_stream(int64_t tape, int64_t op);
+int64_t miseg_tape_bind(int64_t tape, const void* base, int64_t span);
+int64_t miseg_tape_bind_uses(int64_t tape, int64_t slot);
+int miseg_tape_replay(int64_t tape, int64_t segment, const void* const* values, int64_t nvalues);
+int miseg_tape_time_op(int64_t tape, int64_t op);
+int64_t miseg_tape_timed_ms(int64_t tape, int64_t op, float* ms, int64_t cap);
+/* Host <-> device traffic of an iteration as entry points (so that it is on the tape): asynchronous copies between PINNED host
+ * memory and the device on `stream` (the flip decisions and Adam's scalars go up, ref semi_seg/epocher.py:144-149; the meter values
+ * come down, ref :181-185's .item() calls), and the event the host waits for before it reads them. */
+int miseg_upload(void* stream, void* dst_dev, const void* src_pinned, int64_t nbytes);
+int miseg_download(void* stream, void* dst_pinned, const void* src_dev, int64_t nbytes);
+int64_t miseg_event_create(void);
+int miseg_event_destroy(int64_t ev);
+int miseg_event_record(void* stream, void* ev);
+int miseg_event_synchronize(int64_t ev);
+int miseg_event_query(int64_t ev);
+/* Byte movers on `stream` (kernels: hipMemcpyDtoD / hipMemsetAsync can wait behind a busy device's copy queue); pointers 16-byte
+ * aligned.  They stand where the reference's autograd issues zero fills and copies (zero gradient of a part without a loss, a
+ * parameter that received no gradient: torch.optim's zero_grad at ref semi_seg/epocher.py:177). */
+int miseg_fill_zero(void* stream, void* dst, int64_t nbytes);
+int miseg_copy(void* stream, void* dst, const void* src, int64_t nbytes);
+/* Gradient of the logits batch [labeled | unlabeled | flipped unlabeled] (ref semi_seg/epocher.py:154-159 splits it, autograd
+ * scales each loss's gradient by its coefficient, zero-fills the detached part and concatenates): out = [scale0[0] * src0 |
+ * scale1[0] * src1 | scale2[0] * src2], fp32, a null src = zeros, a null scale = 1; numel_i multiples of 4. */
+int miseg_assemble_rows(void* stream, float* out, const float* src0, const float* scale0, int64_t numel0, const float* src1,
+                        const float* scale1, int64_t numel1, const float* src2, const float* scale2, int64_t numel2);
+
+/* ------------------------------------------------------------------------------------------
  * Local (displacement-window) IIC mutual information
  * ref: contrastyou/losses/iic_loss.py:107-149 (IIDSegmentationLoss.__call__),
  *      :152-189 (patch_generator / IIDSegmentationSmallPathLoss).
@@ -152,6 +204,13 @@ int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int6
                          const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S,
                          int64_t K, float T, const float* prob, const float* gprob, void* gfeat, float* gw,
                          float* gb, void* ws, int64_t ws_bytes);
+/* the same with a COMPACT gradient: gfeat_rows = dt [rows][H][W][C] holds rows [row0, row0 + rows) of the batch only, every src[m] must
+ * lie in that range (the epocher's src is the last 2 UB samples, ref semi_seg/epocher.py:258-259): no zero-filled full-batch tensor;
+ * miseg_bn_relu_bwd_dual adds it to the feature's other gradient. */
+int miseg_head_local_bwd_rows(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                              const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S,
+                              int64_t K, float T, const float* prob, const float* gprob, void* gfeat_rows, int64_t row0,
+                              float* gw, float* gb, void* ws, int64_t ws_bytes);
 /* the same, ADDING to gfeat_inout in place of storing (rows of src only; one rounding of the sum): for a tapped feature whose other
  * consumer -- DeConv_1x1 at the last decoder block, unet.py:84,129 -- has already written its input gradient there, so that autograd
  * has nothing left to add (a 300 MB elementwise pass on the step's critical path). */
@@ -167,6 +226,11 @@ int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W,
                           int64_t M, const float* w, int64_t S, int64_t K, float T, const float* pooled,
                           const float* prob, const float* gprob, void* gfeat, float* gw, float* gb,
                           float* dz_ws /* fp32[S*M*K] scratch */);
+/* compact form, as miseg_head_local_bwd_rows */
+int miseg_head_global_bwd_rows(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
+                               int64_t M, const float* w, int64_t S, int64_t K, float T, const float* pooled,
+                               const float* prob, const float* gprob, void* gfeat_rows, int64_t row0, float* gw, float* gb,
+                               float* dz_ws);
 
 /* Head VARIANTS of the same two classes (csrc/heads_var.hip): head_type="mlp" (ref contrastyou/trainer/_utils.py:117-126 global,
  * :154-161 local: Linear/1x1-conv C->HID, LeakyReLU(0.01), Linear/1x1-conv HID->K; HID = 128 global, interm_dim = 64 local) and
@@ -220,6 +284,10 @@ int miseg_softmax_mse(void* stream, const float* a, const float* b, const int32_
  * in_strides4 / out_strides4 are HOST arrays of 4 strides (read at launch time); in, out and flips are device pointers. */
 int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
                const int64_t* in_strides4, const int64_t* out_strides4, int elem_bytes, const int32_t* flips);
+/* The network's input batch out = [a | b | flip(b)] (contiguous [*,C,H,W], 4-byte elements; flips = int32[Nb]) in one pass;
+ * ref semi_seg/epocher.py:148-153 (stack of per-sample flips, then torch.cat of labeled, unlabeled, transformed unlabeled). */
+int miseg_cat_flip(void* stream, const void* a, int64_t Na, const void* b, int64_t Nb, int64_t C, int64_t H, int64_t W,
+                   const int32_t* flips, void* out);
 /* argmax over channels + per-sample per-class intersection/union counts (int64 [N][C] each);
  * ref semi_seg/epocher.py:183 + whl:.../general_dice_meter.py:141-172. pred (int64 [N,H,W]) optional. */
 int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
@@ -254,8 +322,14 @@ int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_
  *   dgrad : is conv3x3_fwd on grad_out with pack kind 1, Cin<->Cout.
  *   wgrad : gw OIHW fp32 [Cout][C0+C1][3][3] (overwritten), deterministic split-K.
  * ------------------------------------------------------------------------------------------ */
+/* kind: 0 = forward layout, 1 = data-gradient layout of input channels [ci_begin, ci_begin + ci_count); kind = (Csrc << 8) (forward
+ * layout only): w_oihw really is [Cout][Csrc][3][3] with Csrc < Cin and the missing input channels are packed as zeros -- the stem,
+ * Conv2d(input_dim = 1, 16, 3) at unet.py:15 read as one 16-byte channel vector. */
 int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w_oihw, int64_t Cout, int64_t Cin, int kind,
                                int64_t ci_begin, int64_t ci_count, void* packed);
+/* ... and the way back for that layer's weight gradient: gw [Cout][Cin][3][3] = the first Cin input channels of the
+ * [Cout][Cin_pad][3][3] gradient miseg_conv3x3_wgrad computed. */
+int miseg_conv3x3_wgrad_slice(void* stream, const float* gw_padded, int64_t Cout, int64_t Cin_pad, int64_t Cin, float* gw);
 /* the same for many layers in ONE launch: jobs_dev = device array of njobs records
  *   struct miseg_pack_job { const float* w_oihw; void* packed; int32_t Cout, Cin, kind, ci_begin, ci_count, first_block; }  (40 bytes)
  * job j owns blocks [first_block[j], first_block[j+1]) of 256 elements each (first_block[0] = 0, ascending);
@@ -329,6 +403,13 @@ int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y,
                            int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
                            int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes,
                            int32_t* sync_counter);
+/* bn_relu_bwd with a SECOND gradient of the activation for samples [n2_begin, n2_end): gy2 = dt [n2_end - n2_begin][H][W][C], added to
+ * gy in fp32 inside the loaders.  A tapped feature map feeds the next layer AND a cluster head (ref semi_seg/epocher.py:258-273, which
+ * takes the last 2 UB samples); the reference's autograd adds the two gradients in a separate pass over the whole batch. */
+int miseg_bn_relu_bwd_dual(void* stream, int dt, const void* raw, const void* gy, const void* gpool, const void* gy2,
+                           int64_t n2_begin, int64_t n2_end, int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma,
+                           const float* saved, int training, void* graw, float* ggamma, float* gbeta, void* ws,
+                           int64_t ws_bytes);
 /* BatchNorm backward folded into the convolutions around it (ref: unet.py:14-21, 31-36 -- what autograd runs as
  * threshold_backward -> native_batch_norm_backward -> convolution_backward becomes two launches per layer):
  *   bn_relu_bwd_stats : the statistics half of bn_relu_bwd for a layer WITHOUT the fused pool: ggamma, gbeta and
@@ -385,7 +466,9 @@ int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float*
                            int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale);
 /* ... and guarded: guard = nguard fp32 flags in device memory (the iteration's deferred assertion / NaN flags); if any of them is
  * non-zero or NaN the launch changes nothing -- parameters and moments stay as the reference, which raises before backward
- * (iic_loss.py:147-148, semi_seg/epocher.py:129-130), would have left them.  nguard == 0: miseg_adam_step_scaled. */
+ * (iic_loss.py:147-148, semi_seg/epocher.py:129-130), would have left them.  nguard == 0: miseg_adam_step_scaled.
+ * grad_scale == 0: the loss scale lives on the device, hyper is fp32[5] and hyper[4] = 1 / scale (a dynamic loss scale under a
+ * replayed launch tape, whose by-value arguments are fixed). */
 int miseg_adam_step_guarded(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale,
                             const float* guard, int64_t nguard);

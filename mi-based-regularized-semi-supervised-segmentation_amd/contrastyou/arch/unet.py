@@ -30,10 +30,7 @@ def _as_dtype(d) -> torch.dtype:
 
 def _cbr(holder_conv: nn.Conv2d, holder_bn: nn.BatchNorm2d, x0: Tensor, x1: Optional[Tensor], training: bool, vec: int,
          ups0: int = 0, ups1: int = 0, want_pool: bool = False):
-    weight = holder_conv.weight
-    cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
-    if weight.shape[1] != cin:  # stem: input was zero-padded to one channel vector
-        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cin - weight.shape[1]))
+    weight = holder_conv.weight     # (the stem's has fewer input channels than the zero-padded activation: the pack kernel pads it)
     return unet_ops.conv_bn_relu(x0, x1, weight, holder_bn.weight, holder_bn.bias, holder_bn.running_mean, holder_bn.running_var,
                                  holder_bn.num_batches_tracked, training, ups0, ups1, want_pool)
 

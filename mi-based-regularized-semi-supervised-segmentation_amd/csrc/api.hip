@@ -44,6 +44,7 @@ static hipEvent_t next_fork_event() {
 }  // namespace miseg_core
 
 extern "C" int miseg_stream_wait_stream(void* waiter, void* producer) {
+    MISEG_TAPE(miseg_stream_wait_stream, waiter, producer);
     if (waiter == producer) return MISEG_OK;
     hipEvent_t ev = miseg_core::next_fork_event();
     if (!ev) return miseg_core::fail(MISEG_E_LAUNCH, "stream_wait_stream: hipEventCreateWithFlags failed");

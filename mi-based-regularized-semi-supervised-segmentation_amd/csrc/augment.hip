@@ -145,6 +145,7 @@ using namespace miseg;
 extern "C" int miseg_augment_slices(void* stream, const uint8_t* atlas_img, const uint8_t* atlas_gt, int64_t n_slices,
                                     int64_t slice_h, int64_t slice_w, const int32_t* jobs_dev, int64_t njobs, int64_t out_h,
                                     int64_t out_w, float* img_out, int64_t* gt_out) {
+    MISEG_TAPE(miseg_augment_slices, stream, atlas_img, atlas_gt, n_slices, slice_h, slice_w, jobs_dev, njobs, out_h, out_w, img_out, gt_out);
     MISEG_REQUIRE(atlas_img && jobs_dev && img_out, "augment_slices: null pointer");
     MISEG_REQUIRE((atlas_gt == nullptr) == (gt_out == nullptr), "augment_slices: label atlas and label output go together");
     MISEG_REQUIRE(n_slices > 0 && slice_h > 0 && slice_w > 0 && slice_h < 32768 && slice_w < 32768, "augment_slices: bad atlas shape");

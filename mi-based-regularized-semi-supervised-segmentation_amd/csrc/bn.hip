@@ -139,9 +139,16 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_pool_kernel(const T* __restri
 //      gives the ReLU mask and, for the pooled layers, the first-max routing.  Pass 1 reads (raw, gy[, gpool]) and reduces
 //      sum(dz), sum(dz*xhat) per block; pass 2 re-reads them and writes graw = a*(dz - b - xhat*c).
 //      One thread = V channels of one pixel (POOL: of one 2x2 window; H, W even).
+// A second gradient of the activation for a contiguous run of samples (pixels [lo, hi) of the batch), added in fp32 in the loader:
+// the tapped feature maps feed the logits layer AND a cluster head (ref semi_seg/epocher.py:258-273), autograd would add the two
+// gradients with an elementwise kernel over the whole batch (and the head would zero-fill the samples it does not touch).
+template <typename T> struct BnGy2 {
+    const T* g;          // null: none; else [hi - lo][C], pixel p of the batch at g + (p - lo) * C
+    int64_t lo, hi;
+};
 template <typename T, bool POOL, typename F>
 __device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T* __restrict__ gy, const T* __restrict__ gpool, int N, int H,
-                                              int W, int C, const float* __restrict__ saved, int64_t first, int64_t step, int cv, F&& f) {
+                                              int W, int C, const float* __restrict__ saved, int64_t first, int64_t step, int cv, BnGy2<T> g2, F&& f) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
     const int CV = C / V;
@@ -154,13 +161,15 @@ __device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T
         // 16 waves x 64 lanes x 32 B = 32 KB outstanding per CU)
         constexpr int U = 4;
         for (int64_t px = first; px < npix; px += U * step) {
-            Raw rr[U], gg[U];
+            Raw rr[U], gg[U], g2v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t pu = px + u * step;
-                const int64_t o = (pu < npix ? pu : px) * CV + cv;
+                const int64_t pc = pu < npix ? pu : px;
+                const int64_t o = pc * CV + cv;
                 rr[u] = reinterpret_cast<const Raw*>(raw)[o];
                 gg[u] = reinterpret_cast<const Raw*>(gy)[o];
+                if (g2.g && pc >= g2.lo && pc < g2.hi) g2v[u] = reinterpret_cast<const Raw*>(g2.g)[(pc - g2.lo) * CV + cv];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -169,6 +178,12 @@ __device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T
                     float fr[V], fg[V], fy[V];
                     VT<T>::unpack(rr[u], fr);
                     VT<T>::unpack(gg[u], fg);
+                    if (g2.g && pu >= g2.lo && pu < g2.hi) {
+                        float f2[V];
+                        VT<T>::unpack(g2v[u], f2);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) fg[i] += f2[i];
+                    }
 #pragma unroll
                     for (int i = 0; i < V; ++i) fy[i] = fmaxf(fr[i] * sc[i] + sh[i], 0.f);
                     VT<T>::unpack(VT<T>::pack(fy), fy);
@@ -210,6 +225,15 @@ __device__ __forceinline__ void bn_dz_foreach(const T* __restrict__ raw, const T
 #pragma unroll
                     for (int i = 0; i < V; ++i) fg[i] = 0.f;
                 }
+                {
+                    const int64_t pq = offs[q] / CV;          // pixel index of this corner of the window
+                    if (g2.g && pq >= g2.lo && pq < g2.hi) {
+                        float f2[V];
+                        VT<T>::unpack(reinterpret_cast<const Raw*>(g2.g)[(pq - g2.lo) * CV + cv], f2);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) fg[i] += f2[i];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     const float g = fg[i] + (arg[i] == q ? gp[i] : 0.f);
@@ -244,7 +268,8 @@ __device__ __forceinline__ void bn_bwd_coeffs(int c, int C, float s1, float s2, 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ raw, const T* __restrict__ gy,
                                                                  const T* __restrict__ gpool, int N, int H, int W, int C,
-                                                                 const float* __restrict__ saved, float* __restrict__ parts, BnBwdFinish fin) {
+                                                                 const float* __restrict__ saved, float* __restrict__ parts, BnBwdFinish fin,
+                                                                 BnGy2<T> g2) {
     constexpr int V = VT<T>::V;
     extern __shared__ float sacc[];  // [256][2*V] transposed reduce
     const int CV = C / V;
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
     float mean[V], invstd[V], a1[V], a2[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { a1[i] = a2[i] = 0.f; mean[i] = saved[cv * V + i]; invstd[i] = saved[C + cv * V + i]; }
-    bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, [&](int64_t, const float* fr, const float* dz) {
+    bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, g2, [&](int64_t, const float* fr, const float* dz) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             a1[i] += dz[i];
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ raw, const T* __restrict__ gy, const T* __restrict__ gpool,
                                                            int N, int H, int W, int C, const float* __restrict__ saved,
-                                                           const float* __restrict__ coeffs, T* __restrict__ graw) {
+                                                           const float* __restrict__ coeffs, T* __restrict__ graw, BnGy2<T> g2) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
     const int CV = C / V;
@@ -330,7 +355,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const int c = cv * V + i;
         mean[i] = saved[c]; invstd[i] = saved[C + c]; ca[i] = coeffs[c]; cb[i] = coeffs[C + c]; cc[i] = coeffs[2 * C + c];
     }
-    bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, [&](int64_t o, const float* fr, const float* dz) {
+    bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, g2, [&](int64_t o, const float* fr, const float* dz) {
         float fd[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -410,6 +435,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     for (int i = 0; i < nguard; ++i)
         if (!(guard[i] == 0.f)) return;
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2], wd = hyper[3];
+    if (inv_scale <= 0.f) inv_scale = hyper[4];      // the loss scale lives on the device (dynamic scale under a replayed launch tape)
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * inv_scale + wd * p[i];
         float mi = m[i] * b1 + (1.f - b1) * gi;
@@ -437,6 +463,7 @@ using namespace miseg;
 
 extern "C" int miseg_bn_finalize(void* stream, const float* parts, int64_t nparts, int64_t C, int64_t count, const float* gamma,
                                  const float* beta, float eps, float momentum, float* rmean, float* rvar, int64_t* nbt, float* saved) {
+    MISEG_TAPE(miseg_bn_finalize, stream, parts, nparts, C, count, gamma, beta, eps, momentum, rmean, rvar, nbt, saved);
     MISEG_REQUIRE(parts && gamma && beta && saved && C > 0 && nparts > 0 && count > 0, "bn_finalize: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), parts, (int)nparts, (int)C, (float)count, gamma,
                        beta, eps, momentum, rmean, rvar, (long long*)nbt, saved);
@@ -446,6 +473,7 @@ extern "C" int miseg_bn_finalize(void* stream, const float* parts, int64_t npart
 
 extern "C" int miseg_bn_eval_coeffs(void* stream, int64_t C, const float* gamma, const float* beta, float eps, const float* rmean,
                                     const float* rvar, float* saved) {
+    MISEG_TAPE(miseg_bn_eval_coeffs, stream, C, gamma, beta, eps, rmean, rvar, saved);
     MISEG_REQUIRE(gamma && beta && rmean && rvar && saved && C > 0, "bn_eval_coeffs: bad args");
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, as_stream(stream), (int)C, gamma, beta, eps, rmean, rvar, saved);
     MISEG_LAUNCH_CHECK("bn_eval_coeffs_kernel");
@@ -454,6 +482,7 @@ extern "C" int miseg_bn_eval_coeffs(void* stream, int64_t C, const float* gamma,
 
 extern "C" int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C, const float* saved,
                                  void* y, void* pooled) {
+    MISEG_TAPE(miseg_bn_relu_fwd, stream, dt, raw, N, H, W, C, saved, y, pooled);
     MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_fwd, stream, MISEG_BF16, raw, N, H, W, C, saved, y, pooled);
     MISEG_REQUIRE(raw && saved && y, "bn_relu_fwd: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
@@ -489,8 +518,10 @@ extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_
 // reduce (+ finalize) (+ apply): graw == null stops after the statistics, which then leave as bwd_coef for the fused loaders of conv.hip
 static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* gy, const void* gpool, int64_t N, int64_t H, int64_t W, int64_t C,
                             const float* gamma, const float* saved, int training, void* graw, float* ggamma, float* gbeta, void* ws,
-                            int64_t ws_bytes, int32_t* sync_counter, float* bwd_coef) {
+                            int64_t ws_bytes, int32_t* sync_counter, float* bwd_coef, const void* gy2 = nullptr, int64_t n2_begin = 0,
+                            int64_t n2_end = 0) {
     MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && (graw || bwd_coef) && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
+    MISEG_REQUIRE(!gy2 || (0 <= n2_begin && n2_begin < n2_end && n2_end <= N && (gy || gpool)), "bn_relu_bwd: bad sample range of the second gradient");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     const int CV = (int)(C / V);
     MISEG_REQUIRE(C % V == 0 && 256 % CV == 0, "bn_relu_bwd: C/%d must divide 256", V);
@@ -507,7 +538,8 @@ static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* g
     const bool finish = sync_counter && C % 4 == 0 && C <= 256 && (int64_t)nb * 2 * C <= kFinishFloats;
     const size_t lb = std::max<size_t>((size_t)256 * 2 * V * 4, finish ? (size_t)(1024 + 2 * C) * 4 : 0);
     BnBwdFinish fin{finish ? reinterpret_cast<unsigned int*>(sync_counter) : nullptr, gamma, coeffs, ggamma, gbeta, (float)npix, training, bwd_coef};
-#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts, fin)
+    const int64_t p2lo = n2_begin * H * W, p2hi = n2_end * H * W;
+#define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts, fin, BnGy2<TT>{(const TT*)gy2, p2lo, p2hi})
     if (dt == MISEG_F32) { if (gpool) RED(float, true); else RED(float, false); }
     else if (dt == MISEG_BF16) { if (gpool) RED(bf16, true); else RED(bf16, false); }
     else return fail(MISEG_E_INVALID, "bn_relu_bwd: bad dtype");
@@ -520,7 +552,7 @@ static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* g
     if (!graw) return MISEG_OK;
     // elementwise pass: many more blocks than the reduce (no partials to bound), same thread -> channel-vector mapping
     const int na = ew_blocks((gpool ? npix / 4 : npix) * CV);
-#define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw)
+#define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw, BnGy2<TT>{(const TT*)gy2, p2lo, p2hi})
     if (dt == MISEG_F32) { if (gpool) APP(float, true); else APP(float, false); }
     else { if (gpool) APP(bf16, true); else APP(bf16, false); }
 #undef APP
@@ -531,6 +563,7 @@ static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* g
 extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
                                       int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
                                       float* ggamma, float* gbeta, void* ws, int64_t ws_bytes, int32_t* sync_counter) {
+    MISEG_TAPE(miseg_bn_relu_bwd_sync, stream, dt, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, sync_counter);
     MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_sync, stream, MISEG_BF16, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws,
                           ws_bytes, sync_counter);
     (void)y;   // kept in the signature; the ReLU mask and pool routing are recomputed from raw (see bn_dz_foreach)
@@ -538,9 +571,20 @@ extern "C" int miseg_bn_relu_bwd_sync(void* stream, int dt, const void* raw, con
     return bn_relu_bwd_impl(stream, dt, raw, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, sync_counter, nullptr);
 }
 
+extern "C" int miseg_bn_relu_bwd_dual(void* stream, int dt, const void* raw, const void* gy, const void* gpool, const void* gy2, int64_t n2_begin,
+                                      int64_t n2_end, int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training,
+                                      void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_bn_relu_bwd_dual, stream, dt, raw, gy, gpool, gy2, n2_begin, n2_end, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes);
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_dual, stream, MISEG_BF16, raw, gy, gpool, gy2, n2_begin, n2_end, N, H, W, C, gamma, saved, training, graw,
+                          ggamma, gbeta, ws, ws_bytes);
+    MISEG_REQUIRE(graw, "bn_relu_bwd_dual: null pointer");
+    return bn_relu_bwd_impl(stream, dt, raw, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, nullptr, nullptr, gy2, n2_begin, n2_end);
+}
+
 extern "C" int miseg_bn_relu_bwd_stats(void* stream, int dt, const void* raw, const void* gy, int64_t N, int64_t H, int64_t W, int64_t C,
                                        const float* gamma, const float* saved, int training, float* bwd_coef, float* ggamma, float* gbeta,
                                        const float* ext_parts, int64_t ext_nparts, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_bn_relu_bwd_stats, stream, dt, raw, gy, N, H, W, C, gamma, saved, training, bwd_coef, ggamma, gbeta, ext_parts, ext_nparts, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_stats, stream, MISEG_BF16, raw, gy, N, H, W, C, gamma, saved, training, bwd_coef, ggamma, gbeta, ext_parts,
                           ext_nparts, ws, ws_bytes);
     MISEG_REQUIRE(bwd_coef, "bn_relu_bwd_stats: null pointer");
@@ -557,10 +601,12 @@ extern "C" int miseg_bn_relu_bwd_stats(void* stream, int dt, const void* raw, co
 extern "C" int miseg_bn_relu_bwd(void* stream, int dt, const void* raw, const void* y, const void* gy, const void* gpool, int64_t N,
                                  int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved, int training, void* graw,
                                  float* ggamma, float* gbeta, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_bn_relu_bwd, stream, dt, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes);
     return miseg_bn_relu_bwd_sync(stream, dt, raw, y, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, nullptr);
 }
 
 extern "C" int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t C, void* out, int accumulate) {
+    MISEG_TAPE(miseg_sumpool2x2, stream, dt, in, N, H, W, C, out, accumulate);
     MISEG_F16_DISPATCH_ON(dt, miseg_sumpool2x2, stream, MISEG_BF16, in, N, H, W, C, out, accumulate);
     MISEG_REQUIRE(in && out && H % 2 == 0 && W % 2 == 0, "sumpool2x2: bad args");
     const int V = dt == MISEG_BF16 ? 8 : 4;
@@ -575,6 +621,7 @@ extern "C" int miseg_sumpool2x2(void* stream, int dt, const void* in, int64_t N,
 }
 
 extern "C" int miseg_axpy(void* stream, int dt, const void* src, void* dst, int64_t numel) {
+    MISEG_TAPE(miseg_axpy, stream, dt, src, dst, numel);
     MISEG_F16_DISPATCH_ON(dt, miseg_axpy, stream, MISEG_BF16, src, dst, numel);
     MISEG_REQUIRE(src && dst, "axpy: null pointer");
     const int V = dt == MISEG_BF16 ? 8 : 4;
@@ -588,6 +635,7 @@ extern "C" int miseg_axpy(void* stream, int dt, const void* src, void* dst, int6
 }
 
 extern "C" int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64_t Cin, int dt_out, void* out, int64_t CP) {
+    MISEG_TAPE(miseg_cast_pad, stream, in, npix, Cin, dt_out, out, CP);
     MISEG_F16_DISPATCH_ON(dt_out, miseg_cast_pad, stream, in, npix, Cin, MISEG_BF16, out, CP);
     MISEG_REQUIRE(in && out && Cin > 0 && CP >= Cin, "cast_pad: bad args");
     hipStream_t st = as_stream(stream);
@@ -602,11 +650,12 @@ extern "C" int miseg_cast_pad(void* stream, const float* in, int64_t npix, int64
 
 extern "C" int miseg_adam_step_guarded(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                                        float beta1, float beta2, const float* hyper, float grad_scale, const float* guard, int64_t nguard) {
+    MISEG_TAPE(miseg_adam_step_guarded, stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, grad_scale, guard, nguard);
     MISEG_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && numel > 0, "adam_step: bad args");
-    MISEG_REQUIRE(grad_scale > 0.f && std::isfinite(grad_scale), "adam_step: grad_scale must be a positive finite number");
+    MISEG_REQUIRE(grad_scale >= 0.f && std::isfinite(grad_scale), "adam_step: grad_scale must be a positive finite number (or 0: read 1 / scale from hyper[4])");
     MISEG_REQUIRE(nguard >= 0 && nguard <= 1024 && (nguard == 0 || guard), "adam_step: bad guard");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(numel)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2,
-                       hyper, 1.f / grad_scale, guard, (int)nguard);
+                       hyper, grad_scale > 0.f ? 1.f / grad_scale : 0.f, guard, (int)nguard);
     MISEG_LAUNCH_CHECK("adam_kernel");
     return MISEG_OK;
 }
@@ -621,6 +670,7 @@ __global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __res
 }  // namespace miseg
 
 extern "C" int miseg_count_nonfinite(void* stream, const float* grad, int64_t numel, float* count) {
+    MISEG_TAPE(miseg_count_nonfinite, stream, grad, numel, count);
     MISEG_REQUIRE(grad && count && numel > 0, "count_nonfinite: bad args");
     hipMemsetAsync(count, 0, sizeof(float), as_stream(stream));
     hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)std::min<int64_t>(cdiv(numel, 1024), 1024)), dim3(256), 0, as_stream(stream), grad, numel, count);
@@ -630,9 +680,11 @@ extern "C" int miseg_count_nonfinite(void* stream, const float* grad, int64_t nu
 
 extern "C" int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                                       float beta1, float beta2, const float* hyper, float grad_scale) {
+    MISEG_TAPE(miseg_adam_step_scaled, stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, grad_scale);
     return miseg_adam_step_guarded(stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, grad_scale, nullptr, 0);
 }
 extern "C" int miseg_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                                float beta1, float beta2, const float* hyper) {
+    MISEG_TAPE(miseg_adam_step, stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper);
     return miseg_adam_step_scaled(stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, 1.f);
 }

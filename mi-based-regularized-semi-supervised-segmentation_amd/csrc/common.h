@@ -19,6 +19,7 @@
 #include "f16_rename.h"
 #endif
 #include "../../include/miseg_hip.h"
+#include "tape.h"
 #ifndef MISEG_F16_BUILD
 #include "f16_protos.h"
 #define MISEG_F16_DISPATCH_ON(var, fn, ...)          \

@@ -717,13 +717,17 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
 // kind 1 (dgrad): n = i - ci_begin (ci_count of them), k = o, tap mirrored (2-ky, 2-kx).
 template <typename T>
 __global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int kind, int ci_begin, int ci_count, T* __restrict__ pk) {
+    // kind >> 8 = input channels the SOURCE tensor really has (0: Cin): the stem's [Cout, 1, 3, 3] weight packed as Cin = one channel
+    // vector, the extra channels zero (forward layout only) -- the host no longer pads the weight with torch ops every step
+    const int csrc = (kind >> 8) ? (kind >> 8) : Cin;
+    kind &= 0xff;
     const int Nn = kind ? ci_count : Cout, Kk = kind ? Cout : Cin;
     const int total = 9 * Nn * Kk;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int k = e % Kk, nn = (e / Kk) % Nn, tap = e / (Kk * Nn);
         const int ky = tap / 3, kx = tap % 3;
         float v;
-        if (!kind) v = w[(((size_t)nn * Cin + k) * 3 + ky) * 3 + kx];
+        if (!kind) v = k < csrc ? w[(((size_t)nn * csrc + k) * 3 + ky) * 3 + kx] : 0.f;
         else v = w[(((size_t)k * Cin + ci_begin + nn) * 3 + (2 - ky)) * 3 + (2 - kx)];
         pk[e] = from_f32<T>(v);
     }
@@ -742,12 +746,14 @@ __global__ __launch_bounds__(256) void pack_w_multi_kernel(const PackJob* __rest
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const PackJob jb = jobs[lo];
+    PackJob jb = jobs[lo];
+    const int csrc = (jb.kind >> 8) ? (jb.kind >> 8) : jb.Cin;      // see pack_w_kernel
+    jb.kind &= 0xff;
     const int Nn = jb.kind ? jb.ci_count : jb.Cout, Kk = jb.kind ? jb.Cout : jb.Cin, total = 9 * Nn * Kk;
     const int e = ((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
     if (e >= total) return;
     const int k = e % Kk, nn = (e / Kk) % Nn, tap = e / (Kk * Nn), ky = tap / 3, kx = tap % 3;
-    const float v = !jb.kind ? jb.w[(((size_t)nn * jb.Cin + k) * 3 + ky) * 3 + kx]
+    const float v = !jb.kind ? (k < csrc ? jb.w[(((size_t)nn * csrc + k) * 3 + ky) * 3 + kx] : 0.f)
                              : jb.w[(((size_t)k * jb.Cin + jb.ci_begin + nn) * 3 + (2 - ky)) * 3 + (2 - kx)];
     reinterpret_cast<T*>(jb.packed)[e] = from_f32<T>(v);
 }
@@ -1289,11 +1295,13 @@ using namespace miseg;
 
 extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, int64_t Cout, int64_t Cin, int kind, int64_t ci_begin,
                                           int64_t ci_count, void* packed) {
+    MISEG_TAPE(miseg_pack_conv3x3_weights, stream, dt, w, Cout, Cin, kind, ci_begin, ci_count, packed);
     MISEG_F16_DISPATCH_ON(dt, miseg_pack_conv3x3_weights, stream, MISEG_BF16, w, Cout, Cin, kind, ci_begin, ci_count, packed);
     MISEG_REQUIRE(w && packed && Cout > 0 && Cin > 0, "pack_conv3x3_weights: bad args");
-    if (!kind) { ci_begin = 0; ci_count = Cin; }
+    MISEG_REQUIRE(kind >= 0 && (kind & 0xff) <= 1 && (kind >> 8) <= Cin && (!(kind >> 8) || !(kind & 0xff)), "pack_conv3x3_weights: bad kind");
+    if (!(kind & 0xff)) { ci_begin = 0; ci_count = Cin; }
     MISEG_REQUIRE(ci_begin >= 0 && ci_count > 0 && ci_begin + ci_count <= Cin, "pack_conv3x3_weights: bad channel slice");
-    const int total = (int)(9 * (kind ? ci_count * Cout : Cout * Cin));
+    const int total = (int)(9 * ((kind & 0xff) ? ci_count * Cout : Cout * Cin));
     const int nb = std::min((total + 255) / 256, 1024);
     if (dt == MISEG_F32)
         hipLaunchKernelGGL(pack_w_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), w, (int)Cout, (int)Cin, kind, (int)ci_begin, (int)ci_count, (float*)packed);
@@ -1305,6 +1313,7 @@ extern "C" int miseg_pack_conv3x3_weights(void* stream, int dt, const float* w, 
 }
 
 extern "C" int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void* jobs_dev, int64_t njobs, int64_t total_blocks) {
+    MISEG_TAPE(miseg_pack_conv3x3_weights_multi, stream, dt, jobs_dev, njobs, total_blocks);
     MISEG_F16_DISPATCH_ON(dt, miseg_pack_conv3x3_weights_multi, stream, MISEG_BF16, jobs_dev, njobs, total_blocks);
     MISEG_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_conv3x3_weights_multi: bad args");
     static_assert(sizeof(PackJob) == 40, "PackJob layout must match miseg_pack_job");
@@ -1314,6 +1323,27 @@ extern "C" int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void
         hipLaunchKernelGGL(pack_w_multi_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), (const PackJob*)jobs_dev, (int)njobs);
     else return fail(MISEG_E_INVALID, "pack_conv3x3_weights_multi: bad dtype");
     MISEG_LAUNCH_CHECK("pack_w_multi_kernel");
+    return MISEG_OK;
+}
+
+// gw[Cout][Cin][9] <- gw_pad[Cout][Cin_pad][9] (first Cin input channels): the stem's weight gradient, computed for one whole channel
+// vector of (zero) input channels, into the parameter's own gradient (ref contrastyou/arch/unet.py:15: Conv2d(input_dim, 16, 3)).
+namespace miseg {
+__global__ __launch_bounds__(256) void slice_cin_kernel(const float* __restrict__ src, int Cout, int Cin_pad, int Cin, float* __restrict__ dst) {
+    const int total = Cout * Cin * 9;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int t = e % 9, ci = (e / 9) % Cin, co = e / (9 * Cin);
+        dst[e] = src[((size_t)co * Cin_pad + ci) * 9 + t];
+    }
+}
+}  // namespace miseg
+extern "C" int miseg_conv3x3_wgrad_slice(void* stream, const float* gw_padded, int64_t Cout, int64_t Cin_pad, int64_t Cin, float* gw) {
+    MISEG_TAPE(miseg_conv3x3_wgrad_slice, stream, gw_padded, Cout, Cin_pad, Cin, gw);
+    MISEG_REQUIRE(gw_padded && gw && Cout > 0 && Cin > 0 && Cin <= Cin_pad, "conv3x3_wgrad_slice: bad args");
+    const int total = (int)(Cout * Cin * 9);
+    hipLaunchKernelGGL(slice_cin_kernel, dim3(std::min((total + 255) / 256, 256)), dim3(256), 0, as_stream(stream), gw_padded, (int)Cout, (int)Cin_pad,
+                       (int)Cin, gw);
+    MISEG_LAUNCH_CHECK("slice_cin_kernel");
     return MISEG_OK;
 }
 
@@ -1463,6 +1493,7 @@ static int conv3x3_fwd_impl(void* stream, int dt, const void* in0, int64_t C0, i
 
 extern "C" int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                                  int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats) {
+    MISEG_TAPE(miseg_conv3x3_fwd, stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats);
     return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, BnFinish{});
 }
@@ -1473,6 +1504,7 @@ extern "C" int64_t miseg_conv3x3_fwd_sumpool_supported(int dt, int64_t Cin, int6
 
 extern "C" int miseg_conv3x3_fwd_sumpool(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
                                          const void* packed_w, int64_t Cout, void* out_pooled) {
+    MISEG_TAPE(miseg_conv3x3_fwd_sumpool, stream, dt, in, Cin, N, H, W, packed_w, Cout, out_pooled);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_sumpool, stream, MISEG_BF16, in, Cin, N, H, W, packed_w, Cout, out_pooled);
     return conv3x3_fwd_impl(stream, dt, in, Cin, 0, nullptr, 0, 0, N, H, W, packed_w, Cout, out_pooled, nullptr, BnFinish{}, true);
 }
@@ -1483,6 +1515,7 @@ extern "C" int64_t miseg_conv3x3_fwd_sumpool_acc_supported(int dt, int64_t Cin, 
 
 extern "C" int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* in, int64_t Cin, int64_t N, int64_t H, int64_t W,
                                              const void* packed_w, int64_t Cout, void* inout_pooled) {
+    MISEG_TAPE(miseg_conv3x3_fwd_sumpool_acc, stream, dt, in, Cin, N, H, W, packed_w, Cout, inout_pooled);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_sumpool_acc, stream, MISEG_BF16, in, Cin, N, H, W, packed_w, Cout, inout_pooled);
     MISEG_REQUIRE(miseg_conv3x3_fwd_sumpool_acc_supported(dt, Cin, N, H, W), "conv3x3_fwd_sumpool_acc: streaming shapes only");
     BnFinish opt{};
@@ -1493,6 +1526,7 @@ extern "C" int miseg_conv3x3_fwd_sumpool_acc(void* stream, int dt, const void* i
 // ---- data gradient of a convolution over the channel concat of two full-resolution sources: ONE launch, two destinations
 extern "C" int miseg_conv3x3_dgrad_dual(void* stream, int dt, const void* graw, int64_t K, int64_t N, int64_t H, int64_t W, const void* packed_w,
                                         int64_t C0, void* out0, int64_t C1, void* out1) {
+    MISEG_TAPE(miseg_conv3x3_dgrad_dual, stream, dt, graw, K, N, H, W, packed_w, C0, out0, C1, out1);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_dgrad_dual, stream, MISEG_BF16, graw, K, N, H, W, packed_w, C0, out0, C1, out1);
     MISEG_REQUIRE(out0 && out1 && C0 > 0 && C1 > 0 && C0 % 16 == 0 && C1 % 4 == 0, "conv3x3_dgrad_dual: the first source must have a multiple of "
                   "16 channels, the second a multiple of 4");
@@ -1520,6 +1554,7 @@ extern "C" int64_t miseg_conv3x3_dgrad_red_parts(int dt, int64_t K, int64_t N, i
 extern "C" int miseg_conv3x3_dgrad_bn(void* stream, int dt, const void* raw_or_graw, const void* gy, const float* bwd_coef, int64_t K,
                                       int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cs, void* out, int pool_out,
                                       const void* red_raw, const float* red_saved, float* red_parts) {
+    MISEG_TAPE(miseg_conv3x3_dgrad_bn, stream, dt, raw_or_graw, gy, bwd_coef, K, N, H, W, packed_w, Cs, out, pool_out, red_raw, red_saved, red_parts);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_dgrad_bn, stream, MISEG_BF16, raw_or_graw, gy, bwd_coef, K, N, H, W, packed_w, Cs, out, pool_out, red_raw,
                           red_saved, red_parts);
     MISEG_REQUIRE(!gy || bwd_coef, "conv3x3_dgrad_bn: coefficients missing");
@@ -1542,6 +1577,7 @@ extern "C" int miseg_conv3x3_bn_fwd(void* stream, int dt, const void* in0, int64
                                     int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, float* stats,
                                     const float* gamma, const float* beta, float eps, float momentum, float* rmean, float* rvar,
                                     int64_t* nbt, float* saved, int32_t* sync_counter) {
+    MISEG_TAPE(miseg_conv3x3_bn_fwd, stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, gamma, beta, eps, momentum, rmean, rvar, nbt, saved, sync_counter);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_bn_fwd, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, stats, gamma, beta,
                           eps, momentum, rmean, rvar, nbt, saved, sync_counter);
     MISEG_REQUIRE(stats && gamma && beta && saved && sync_counter, "conv3x3_bn_fwd: null pointer");
@@ -1614,6 +1650,7 @@ static int conv3x3_wgrad_impl(void* stream, int dt, const void* in0, int64_t C0,
 
 extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                                    int64_t N, int64_t H, int64_t W, const void* gout, int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_conv3x3_wgrad, stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_wgrad, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes);
     return conv3x3_wgrad_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, gout, Cout, gw, ws, ws_bytes, BnLoad{nullptr, nullptr});
 }
@@ -1621,6 +1658,7 @@ extern "C" int miseg_conv3x3_wgrad(void* stream, int dt, const void* in0, int64_
 extern "C" int miseg_conv3x3_wgrad_bn(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                                       int64_t N, int64_t H, int64_t W, const void* raw, const void* gy, const float* bwd_coef, int64_t Cout,
                                       float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_conv3x3_wgrad_bn, stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, raw, gy, bwd_coef, Cout, gw, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_wgrad_bn, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, raw, gy, bwd_coef, Cout, gw, ws, ws_bytes);
     MISEG_REQUIRE(gy && bwd_coef, "conv3x3_wgrad_bn: null pointer");
     MISEG_REQUIRE(Cout % (dt == MISEG_F32 ? 4 : 8) == 0, "conv3x3_wgrad_bn: Cout must be a whole number of 16-byte vectors");
@@ -1629,6 +1667,7 @@ extern "C" int miseg_conv3x3_wgrad_bn(void* stream, int dt, const void* in0, int
 
 extern "C" int miseg_conv1x1_fwd(void* stream, int dt, const void* in, int64_t N, int64_t H, int64_t W, int64_t Cin, const float* w,
                                  const float* bias, int64_t Cout, float* out) {
+    MISEG_TAPE(miseg_conv1x1_fwd, stream, dt, in, N, H, W, Cin, w, bias, Cout, out);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv1x1_fwd, stream, MISEG_BF16, in, N, H, W, Cin, w, bias, Cout, out);
     MISEG_REQUIRE(in && w && bias && out, "conv1x1_fwd: null pointer");
     MISEG_REQUIRE(Cin == 16, "conv1x1_fwd: Cin must be 16 (unet.py:84)");
@@ -1656,6 +1695,7 @@ extern "C" int64_t miseg_conv1x1_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, i
 
 extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const float* gout, int64_t N, int64_t H, int64_t W, int64_t Cin,
                                  const float* w, int64_t Cout, void* gin, float* gw, float* gbias, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_conv1x1_bwd, stream, dt, in, gout, N, H, W, Cin, w, Cout, gin, gw, gbias, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv1x1_bwd, stream, MISEG_BF16, in, gout, N, H, W, Cin, w, Cout, gin, gw, gbias, ws, ws_bytes);
     MISEG_REQUIRE(in && gout && w && gw && gbias && ws, "conv1x1_bwd: null pointer");
     MISEG_REQUIRE(Cin == 16, "conv1x1_bwd: Cin must be 16");

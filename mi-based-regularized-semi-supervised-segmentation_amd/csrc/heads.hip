@@ -830,6 +830,7 @@ template <int C> static size_t head_mfma_lds(int64_t S) { return (size_t)(kHT / 
 extern "C" int miseg_head_local_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
                                     int64_t K, float T, float* prob, float simplex_tol, int32_t* simplex_violations) {
+    MISEG_TAPE(miseg_head_local_fwd, stream, dt, feat, B, H, W, C, src, flips, M, w, b, S, K, T, prob, simplex_tol, simplex_violations);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_fwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, b, S, K, T, prob, simplex_tol, simplex_violations);
     MISEG_REQUIRE(feat && src && w && b && prob, "head_local_fwd: null pointer");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && K > 0 && K <= 64 && M > 0 && S > 0 && H > 0 && W > 0, "head_local_fwd: need C%%4==0, K<=64");
@@ -894,14 +895,28 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
                                     float T, const float* prob, const float* gprob, void* gfeat, float* gw, float* gb, void* ws,
                                     int64_t ws_bytes) {
+    MISEG_TAPE(miseg_head_local_bwd, stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes);
     return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes, 0);
+}
+
+// gfeat_rows holds rows [row0, row0 + rows) of the batch only (src[] must lie inside): see miseg_hip.h
+extern "C" int miseg_head_local_bwd_rows(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                         const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
+                                         float T, const float* prob, const float* gprob, void* gfeat_rows, int64_t row0, float* gw, float* gb,
+                                         void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_head_local_bwd_rows, stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_rows, row0, gw, gb, ws, ws_bytes);
+    MISEG_REQUIRE(row0 >= 0 && row0 < B, "head_local_bwd_rows: bad first row");
+    const int64_t es = dt == MISEG_F32 ? 4 : 2;
+    void* base = gfeat_rows ? static_cast<char*>(gfeat_rows) - row0 * H * W * C * es : nullptr;      // row src[m] of the batch = row src[m] - row0 here
+    return miseg_head_local_bwd(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, base, gw, gb, ws, ws_bytes);
 }
 
 extern "C" int miseg_head_local_bwd_acc(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                         const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
                                         float T, const float* prob, const float* gprob, void* gfeat_inout, float* gw, float* gb, void* ws,
                                         int64_t ws_bytes) {
+    MISEG_TAPE(miseg_head_local_bwd_acc, stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd_acc, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes);
     MISEG_REQUIRE(gfeat_inout, "head_local_bwd_acc: null gradient tensor");
     return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes, 1);

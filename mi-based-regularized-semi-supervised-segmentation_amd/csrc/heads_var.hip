@@ -390,6 +390,7 @@ extern "C" int miseg_head_local_var_fwd(void* stream, int dt, const void* feat, 
                                         const int32_t* src, const int32_t* flips, int64_t M, const float* w1, const float* b1,
                                         int64_t HID, const float* w2, const float* b2, int64_t S, int64_t K, float T, int normalize,
                                         float* prob) {
+    MISEG_TAPE(miseg_head_local_var_fwd, stream, dt, feat, B, H, W, C, src, flips, M, w1, b1, HID, w2, b2, S, K, T, normalize, prob);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_var_fwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w1, b1, HID, w2, b2, S, K, T, normalize, prob);
     VAR_COMMON_CHECKS("head_local_var_fwd");
     MISEG_REQUIRE(feat && src && prob && B > 0 && H > 0 && W > 0, "head_local_var_fwd: null pointer / bad shape");
@@ -420,6 +421,7 @@ extern "C" int miseg_head_local_var_bwd(void* stream, int dt, const void* feat, 
                                         int64_t HID, const float* w2, const float* b2, int64_t S, int64_t K, float T, int normalize,
                                         const float* gprob, void* gfeat, float* gw1, float* gb1, float* gw2, float* gb2, void* ws,
                                         int64_t ws_bytes) {
+    MISEG_TAPE(miseg_head_local_var_bwd, stream, dt, feat, B, H, W, C, src, flips, M, w1, b1, HID, w2, b2, S, K, T, normalize, gprob, gfeat, gw1, gb1, gw2, gb2, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_var_bwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w1, b1, HID, w2, b2, S, K, T, normalize, gprob, gfeat, gw1, gb1, gw2, gb2, ws, ws_bytes);
     VAR_COMMON_CHECKS("head_local_var_bwd");
     MISEG_REQUIRE(feat && src && gprob && gw1 && gb1 && (HID == 0 || (gw2 && gb2)) && ws, "head_local_var_bwd: null pointer");
@@ -451,6 +453,7 @@ extern "C" int miseg_head_local_var_bwd(void* stream, int dt, const void* feat, 
 extern "C" int miseg_head_global_var_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                          const int32_t* src, int64_t M, const float* w1, const float* b1, int64_t HID, const float* w2,
                                          const float* b2, int64_t S, int64_t K, float T, int normalize, float* pooled, float* prob) {
+    MISEG_TAPE(miseg_head_global_var_fwd, stream, dt, feat, B, H, W, C, src, M, w1, b1, HID, w2, b2, S, K, T, normalize, pooled, prob);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_global_var_fwd, stream, MISEG_BF16, feat, B, H, W, C, src, M, w1, b1, HID, w2, b2, S, K, T, normalize, pooled, prob);
     VAR_COMMON_CHECKS("head_global_var_fwd");
     MISEG_REQUIRE(feat && src && pooled && prob && B > 0 && H > 0 && W > 0, "head_global_var_fwd: null pointer / bad shape");
@@ -473,6 +476,7 @@ extern "C" int miseg_head_global_var_bwd(void* stream, int dt, int64_t B, int64_
                                          const float* w1, const float* b1, int64_t HID, const float* w2, const float* b2, int64_t S,
                                          int64_t K, float T, int normalize, const float* pooled, const float* gprob, void* gfeat,
                                          float* gw1, float* gb1, float* gw2, float* gb2, float* dpool_ws) {
+    MISEG_TAPE(miseg_head_global_var_bwd, stream, dt, B, H, W, C, src, M, w1, b1, HID, w2, b2, S, K, T, normalize, pooled, gprob, gfeat, gw1, gb1, gw2, gb2, dpool_ws);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_global_var_bwd, stream, MISEG_BF16, B, H, W, C, src, M, w1, b1, HID, w2, b2, S, K, T, normalize, pooled, gprob, gfeat, gw1, gb1, gw2, gb2, dpool_ws);
     VAR_COMMON_CHECKS("head_global_var_bwd");
     MISEG_REQUIRE(src && pooled && gprob && gw1 && gb1 && (HID == 0 || (gw2 && gb2)) && dpool_ws, "head_global_var_bwd: null pointer");

@@ -240,6 +240,7 @@ using namespace miseg;
 
 extern "C" int miseg_report_scalars(void* stream, const float* flat, const int32_t* iflat, const float* coeff, int64_t R, int64_t C,
                                     const int32_t* desc, int64_t ncheck, float* out) {
+    MISEG_TAPE(miseg_report_scalars, stream, flat, iflat, coeff, R, C, desc, ncheck, out);
     MISEG_REQUIRE(out && R >= 0 && C >= 0 && ncheck >= 0 && R + ncheck > 0, "report_scalars: bad sizes");
     MISEG_REQUIRE((R == 0 || (coeff && (C == 0 || flat))) && (ncheck == 0 || desc), "report_scalars: null pointer");
     hipLaunchKernelGGL(report_scalars_kernel, dim3(1), dim3(256), 0, as_stream(stream), flat, iflat, coeff, (int)R, (int)C, desc, (int)ncheck, out);
@@ -249,6 +250,7 @@ extern "C" int miseg_report_scalars(void* stream, const float* flat, const int32
 
 extern "C" int miseg_simplex_violations(void* stream, const float* x, int64_t outer, int64_t C, int64_t inner, float tol,
                                         int32_t* count) {
+    MISEG_TAPE(miseg_simplex_violations, stream, x, outer, C, inner, tol, count);
     MISEG_REQUIRE(x && count, "simplex_violations: null pointer");
     MISEG_REQUIRE(outer > 0 && C > 0 && inner > 0 && C < (1 << 20), "simplex_violations: bad shape");
     const int64_t total = outer * inner;
@@ -275,6 +277,7 @@ extern "C" int64_t miseg_loss_ws_bytes(int64_t N, int64_t H, int64_t W) { return
 
 extern "C" int miseg_softmax_kl(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W, int64_t C,
                                 const float* upstream, float* loss, float* glogits, int32_t* bad_label, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_softmax_kl, stream, logits, labels, N, H, W, C, upstream, loss, glogits, bad_label, ws, ws_bytes);
     MISEG_REQUIRE(logits && labels && loss && bad_label && ws, "softmax_kl: null pointer");
     const int64_t npix = N * H * W;
     MISEG_REQUIRE(npix > 0 && ws_bytes >= miseg_loss_ws_bytes(N, H, W), "softmax_kl: bad shape / workspace");
@@ -291,6 +294,7 @@ extern "C" int miseg_softmax_kl(void* stream, const float* logits, const int64_t
 
 extern "C" int miseg_softmax_mse(void* stream, const float* a, const float* b, const int32_t* flips, int64_t N, int64_t H, int64_t W,
                                  int64_t C, const float* upstream, float* loss, float* ga, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_softmax_mse, stream, a, b, flips, N, H, W, C, upstream, loss, ga, ws, ws_bytes);
     MISEG_REQUIRE(a && b && loss && ws, "softmax_mse: null pointer");
     const int64_t npix = N * H * W;
     MISEG_REQUIRE(npix > 0 && ws_bytes >= miseg_loss_ws_bytes(N, H, W), "softmax_mse: bad shape / workspace");
@@ -307,6 +311,7 @@ extern "C" int miseg_softmax_mse(void* stream, const float* a, const float* b, c
 
 extern "C" int miseg_softmax_klcons(void* stream, const float* a, const float* b, const int32_t* flips, int64_t N, int64_t H, int64_t W,
                                     int64_t C, const float* upstream, float* loss, float* ga, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_softmax_klcons, stream, a, b, flips, N, H, W, C, upstream, loss, ga, ws, ws_bytes);
     MISEG_REQUIRE(a && b && loss && ws, "softmax_klcons: null pointer");
     const int64_t npix = N * H * W;
     MISEG_REQUIRE(npix > 0 && ws_bytes >= miseg_loss_ws_bytes(N, H, W), "softmax_klcons: bad shape / workspace");
@@ -323,6 +328,20 @@ extern "C" int miseg_softmax_klcons(void* stream, const float* a, const float* b
 
 extern "C" int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
                           const int64_t* is, const int64_t* os, int elem_bytes, const int32_t* flips) {
+    // the stride arrays are HOST memory read during this call: a recorded call keeps its own copy of them
+    ::miseg_core::TapeScope miseg_tape_scope_;
+#ifndef MISEG_F16_BUILD
+    if (::miseg_core::tape_depth == 1 && ::miseg_core::tape_recording() && is && os) {
+        auto* op = new ::miseg_core::TapeFnOp();
+        struct Call { void* stream; const void* in; void* out; int64_t n, c, h, w, is[4], os[4]; int eb; const int32_t* flips; };
+        auto call = std::make_shared<Call>(Call{stream, in, out, N, C, H, W, {is[0], is[1], is[2], is[3]}, {os[0], os[1], os[2], os[3]}, elem_bytes, flips});
+        op->name = "miseg_flip";
+        op->stream = stream;
+        op->fn = [call]() { return miseg_flip(call->stream, call->in, call->out, call->n, call->c, call->h, call->w, call->is, call->os, call->eb, call->flips); };
+        op->ptrs = {&call->in, const_cast<const void**>(reinterpret_cast<void**>(&call->out)), reinterpret_cast<const void**>(&call->flips)};
+        ::miseg_core::tape_push(op);
+    }
+#endif
     MISEG_REQUIRE(in && out && is && os && flips, "flip: null pointer");
     MISEG_REQUIRE(in != out, "flip: in-place not supported");
     const int64_t total = N * C * H * W;
@@ -339,8 +358,41 @@ extern "C" int miseg_flip(void* stream, const void* in, void* out, int64_t N, in
     return MISEG_OK;
 }
 
+// out = [a | b | flip(b)] along the batch dimension (contiguous [*, C, H, W], 4-byte elements): the network's input batch
+// (ref semi_seg/epocher.py:148-153: stack of per-sample flips, then torch.cat) in one pass.
+namespace miseg {
+__global__ __launch_bounds__(256) void cat_flip_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, int Na,
+                                                      int Nb, int C, int H, int W, const int32_t* __restrict__ flips) {
+    const int64_t per = (int64_t)C * H * W, total = (int64_t)(Na + 2 * Nb) * per;
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e / per, r = e - n * per;
+        uint32_t v;
+        if (n < Na) v = a[e];
+        else if (n < Na + Nb) v = b[e - (int64_t)Na * per];
+        else {
+            const int m = (int)(n - Na - Nb), f = flips[m];
+            const int w = r % W, h = (r / W) % H, c = r / ((int64_t)W * H);
+            const int hs = (f & 1) ? H - 1 - h : h, wsrc = (f & 2) ? W - 1 - w : w;
+            v = b[(int64_t)m * per + ((int64_t)c * H + hs) * W + wsrc];
+        }
+        out[e] = v;
+    }
+}
+}  // namespace miseg
+extern "C" int miseg_cat_flip(void* stream, const void* a, int64_t Na, const void* b, int64_t Nb, int64_t C, int64_t H, int64_t W,
+                              const int32_t* flips, void* out) {
+    MISEG_TAPE(miseg_cat_flip, stream, a, Na, b, Nb, C, H, W, flips, out);
+    MISEG_REQUIRE(out && flips && (a || Na == 0) && b && Na >= 0 && Nb > 0 && C > 0 && H > 0 && W > 0, "cat_flip: bad args");
+    const int64_t total = (Na + 2 * Nb) * C * H * W;
+    hipLaunchKernelGGL(cat_flip_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, as_stream(stream), (const uint32_t*)a,
+                       (const uint32_t*)b, (uint32_t*)out, (int)Na, (int)Nb, (int)C, (int)H, (int)W, flips);
+    MISEG_LAUNCH_CHECK("cat_flip_kernel");
+    return MISEG_OK;
+}
+
 extern "C" int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W, int64_t C,
                                  int64_t* pred, int64_t* inter, int64_t* uni) {
+    MISEG_TAPE(miseg_argmax_dice, stream, logits, labels, N, H, W, C, pred, inter, uni);
     MISEG_REQUIRE(logits && (pred || labels), "argmax_dice: null pointer");
     MISEG_REQUIRE(!labels || (inter && uni), "argmax_dice: labels need inter/uni outputs");
     hipStream_t st = as_stream(stream);

@@ -292,6 +292,7 @@ using namespace miseg;
 
 extern "C" int miseg_iic_global_joint_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, int symmetric,
                                           float* joint) {
+    MISEG_TAPE(miseg_iic_global_joint_fwd, stream, x, y, S, N, K, symmetric, joint);
     MISEG_REQUIRE(x && y && joint, "iic_global_joint_fwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_joint_fwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_joint_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, symmetric, joint);
@@ -301,6 +302,7 @@ extern "C" int miseg_iic_global_joint_fwd(void* stream, const float* x, const fl
 
 extern "C" int miseg_iic_global_joint_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, int symmetric,
                                           const float* joint, const float* gjoint, float* gx, float* gy) {
+    MISEG_TAPE(miseg_iic_global_joint_bwd, stream, x, y, S, N, K, symmetric, joint, gjoint, gx, gy);
     MISEG_REQUIRE(x && y && joint && gjoint && gx && gy, "iic_global_joint_bwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_joint_bwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_joint_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, symmetric, joint, gjoint,
@@ -311,6 +313,7 @@ extern "C" int miseg_iic_global_joint_bwd(void* stream, const float* x, const fl
 
 extern "C" int miseg_iic_global_fwd_pair(void* stream, const float* prob, int64_t S, int64_t N, int64_t K, float lamb, float* loss,
                                          float* loss_no_lamb, float* joint) {
+    MISEG_TAPE(miseg_iic_global_fwd_pair, stream, prob, S, N, K, lamb, loss, loss_no_lamb, joint);
     MISEG_REQUIRE(prob && loss && loss_no_lamb && joint, "iic_global_fwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_fwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_global_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), prob, prob + N * K, (int)N, (int)K, lamb, loss,
@@ -321,6 +324,7 @@ extern "C" int miseg_iic_global_fwd_pair(void* stream, const float* prob, int64_
 
 extern "C" int miseg_iic_global_bwd_pair(void* stream, const float* prob, int64_t S, int64_t N, int64_t K, float lamb, const float* upstream,
                                          float* gprob) {
+    MISEG_TAPE(miseg_iic_global_bwd_pair, stream, prob, S, N, K, lamb, upstream, gprob);
     MISEG_REQUIRE(prob && gprob, "iic_global_bwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_bwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), prob, prob + N * K, (int)N, (int)K, lamb,
@@ -331,6 +335,7 @@ extern "C" int miseg_iic_global_bwd_pair(void* stream, const float* prob, int64_
 
 extern "C" int miseg_iic_global_fwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, float lamb,
                                     float* loss, float* loss_no_lamb, float* joint) {
+    MISEG_TAPE(miseg_iic_global_fwd, stream, x, y, S, N, K, lamb, loss, loss_no_lamb, joint);
     MISEG_REQUIRE(x && y && loss && loss_no_lamb && joint, "iic_global_fwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_fwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_global_fwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, lamb, loss,
@@ -341,6 +346,7 @@ extern "C" int miseg_iic_global_fwd(void* stream, const float* x, const float* y
 
 extern "C" int miseg_iic_global_bwd(void* stream, const float* x, const float* y, int64_t S, int64_t N, int64_t K, float lamb,
                                     const float* upstream, float* gx, float* gy) {
+    MISEG_TAPE(miseg_iic_global_bwd, stream, x, y, S, N, K, lamb, upstream, gx, gy);
     MISEG_REQUIRE(x && y && gx && gy, "iic_global_bwd: null pointer");
     MISEG_REQUIRE(S > 0 && N > 0 && K > 0 && K <= kMaxK, "iic_global_bwd: need 0<K<=%d", kMaxK);
     hipLaunchKernelGGL(iic_global_bwd_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), x, y, (int)N, (int)K, lamb,
@@ -352,6 +358,7 @@ extern "C" int miseg_iic_global_bwd(void* stream, const float* x, const float* y
 extern "C" int miseg_head_global_fwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                      const int32_t* src, int64_t M, const float* w, const float* b, int64_t S, int64_t K, float T,
                                      float* pooled, float* prob) {
+    MISEG_TAPE(miseg_head_global_fwd, stream, dt, feat, B, H, W, C, src, M, w, b, S, K, T, pooled, prob);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_global_fwd, stream, MISEG_BF16, feat, B, H, W, C, src, M, w, b, S, K, T, pooled, prob);
     MISEG_REQUIRE(feat && src && w && b && pooled && prob, "head_global_fwd: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_fwd: bad shape (K<=64)");
@@ -368,7 +375,21 @@ extern "C" int miseg_head_global_fwd(void* stream, int dt, const void* feat, int
 
 extern "C" int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src, int64_t M,
                                      const float* w, int64_t S, int64_t K, float T, const float* pooled, const float* prob,
+                                     const float* gprob, void* gfeat, float* gw, float* gb, float* dz_ws);
+extern "C" int miseg_head_global_bwd_rows(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src, int64_t M,
+                                          const float* w, int64_t S, int64_t K, float T, const float* pooled, const float* prob,
+                                          const float* gprob, void* gfeat_rows, int64_t row0, float* gw, float* gb, float* dz_ws) {
+    MISEG_TAPE(miseg_head_global_bwd_rows, stream, dt, B, H, W, C, src, M, w, S, K, T, pooled, prob, gprob, gfeat_rows, row0, gw, gb, dz_ws);
+    MISEG_REQUIRE(row0 >= 0 && row0 < B, "head_global_bwd_rows: bad first row");
+    const int64_t es = dt == MISEG_F32 ? 4 : 2;
+    void* base = gfeat_rows ? static_cast<char*>(gfeat_rows) - row0 * H * W * C * es : nullptr;
+    return miseg_head_global_bwd(stream, dt, B, H, W, C, src, M, w, S, K, T, pooled, prob, gprob, base, gw, gb, dz_ws);
+}
+
+extern "C" int miseg_head_global_bwd(void* stream, int dt, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src, int64_t M,
+                                     const float* w, int64_t S, int64_t K, float T, const float* pooled, const float* prob,
                                      const float* gprob, void* gfeat, float* gw, float* gb, float* dz_ws) {
+    MISEG_TAPE(miseg_head_global_bwd, stream, dt, B, H, W, C, src, M, w, S, K, T, pooled, prob, gprob, gfeat, gw, gb, dz_ws);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_global_bwd, stream, MISEG_BF16, B, H, W, C, src, M, w, S, K, T, pooled, prob, gprob, gfeat, gw, gb, dz_ws);
     MISEG_REQUIRE(src && w && pooled && prob && gprob && gw && gb && dz_ws, "head_global_bwd: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && M > 0 && S > 0 && C > 0, "head_global_bwd: bad shape");

@@ -653,6 +653,7 @@ extern "C" int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t 
 extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const float* y, const float* mask, int64_t N,
                                          int64_t K, int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P,
                                          float* raw, void* ws, int64_t ws_bytes, int precision) {
+    MISEG_TAPE(miseg_iic_local_joint_fwd, stream, x, y, mask, N, K, H, W, pad, win, P, raw, ws, ws_bytes, precision);
     MISEG_REQUIRE(x && y && win && raw && ws, "iic_local_joint_fwd: null pointer");
     MISEG_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_joint_fwd: bad shape");
     JointGeom g;
@@ -683,6 +684,7 @@ extern "C" int miseg_iic_local_joint_fwd(void* stream, const float* x, const flo
 extern "C" int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
                                                int64_t pad, const int32_t* win, int64_t P, float* raw, void* ws, int64_t ws_bytes,
                                                int precision) {
+    MISEG_TAPE(miseg_iic_local_joint_fwd_heads, stream, probs, S, UB, K, H, W, pad, win, P, raw, ws, ws_bytes, precision);
     MISEG_REQUIRE(probs && win && raw && ws, "iic_local_joint_fwd_heads: null pointer");
     MISEG_REQUIRE(S > 0 && UB > 0 && K > 0 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_joint_fwd_heads: bad shape");
     const int64_t hs = 2 * UB * K * H * W, TT = (2 * pad + 1) * (2 * pad + 1);
@@ -712,6 +714,7 @@ extern "C" int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs,
 extern "C" int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
                                          int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
                                          float* gprob, int accumulate, int precision, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_iic_local_bwd_heads, stream, probs, S, UB, K, H, W, pad, win, P, grad_raw, scale, gprob, accumulate, precision, ws, ws_bytes);
     MISEG_REQUIRE(probs && win && grad_raw && scale && gprob, "iic_local_bwd_heads: null pointer");
     MISEG_REQUIRE(S > 0 && UB > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_bwd_heads: bad shape (K<=32)");
     const int64_t hs = 2 * UB * K * H * W, half = UB * K * H * W, TT = (2 * pad + 1) * (2 * pad + 1);
@@ -739,6 +742,7 @@ extern "C" int64_t miseg_iic_local_loss_ws_bytes(int64_t pad, int64_t P) { retur
 
 extern "C" int miseg_iic_local_loss_fwd_ws(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
                                            float* loss, float* grad_raw, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_iic_local_loss_fwd_ws, stream, raw, K, pad, P, lamda, loss, grad_raw, ws, ws_bytes);
     MISEG_REQUIRE(raw && loss && grad_raw && ws, "iic_local_loss_fwd_ws: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && pad >= 0 && P > 0, "iic_local_loss_fwd_ws: bad shape");
     MISEG_REQUIRE(ws_bytes >= miseg_iic_local_loss_ws_bytes(pad, P), "iic_local_loss_fwd_ws: workspace too small");
@@ -754,6 +758,7 @@ extern "C" int miseg_iic_local_loss_fwd_ws(void* stream, const float* raw, int64
 
 extern "C" int miseg_iic_local_loss_fwd(void* stream, const float* raw, int64_t K, int64_t pad, int64_t P, float lamda,
                                         float* loss, float* grad_raw) {
+    MISEG_TAPE(miseg_iic_local_loss_fwd, stream, raw, K, pad, P, lamda, loss, grad_raw);
     MISEG_REQUIRE(raw && loss && grad_raw, "iic_local_loss_fwd: null pointer");
     MISEG_REQUIRE(K > 0 && K <= 64 && pad >= 0 && P > 0, "iic_local_loss_fwd: bad shape");
     const int T = 2 * (int)pad + 1;
@@ -770,6 +775,7 @@ extern "C" int miseg_iic_local_bwd(void* stream, const float* x, const float* y,
                                    int64_t H, int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw,
                                    const float* scale, float* gx, float* gy, int accumulate, int precision,
                                    void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_iic_local_bwd, stream, x, y, mask, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, precision, ws, ws_bytes);
     MISEG_REQUIRE(x && y && win && grad_raw && scale && gx && gy, "iic_local_bwd: null pointer");
     MISEG_REQUIRE(N > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && pad >= 0 && P > 0, "iic_local_bwd: bad shape (K<=32)");
     hipStream_t st = as_stream(stream);

@@ -106,11 +106,15 @@ class KernelTimer:
 
 
 TIMER = None  # set to a KernelTimer by bench.py
+RECORDING = 0         # handle of the launch tape being recorded (miseg_amd.tape.StepTape), else 0
+TAPE_TAGS: list = []  # while recording: (op index, tag, (flops, bytes)) of every tagged call -- bench.py times tagged ops of a replayed tape
 
 
 def call(name: str, *args, work=None, tag=None) -> None:
     """Invoke an int-returning entry point and turn a negative status into an exception."""
     fn = getattr(lib(), name)
+    if RECORDING and work is not None:
+        TAPE_TAGS.append((int(lib().miseg_tape_len(RECORDING)), tag or name, work))
     if TIMER is not None and work is not None:
         box = []
         TIMER.wrap(tag or name, work, lambda: box.append(fn(*args)))

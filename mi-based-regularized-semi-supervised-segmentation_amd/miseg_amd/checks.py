@@ -88,7 +88,8 @@ def simplex_violations(t: Tensor, axis: int = 1, tol: float = 2e-4) -> Tensor:
     inner = 1
     for d in t.shape[axis + 1:]:
         inner *= d
-    count = torch.zeros((), dtype=torch.int32, device=t.device)
+    from .ops import zero_counter
+    count = zero_counter(t.device)         # inside an iteration: a counter of the step block (zeroed by its upload), else torch.zeros
     if t.numel():
         call("miseg_simplex_violations", torch.cuda.current_stream().cuda_stream, t.data_ptr(), outer, t.shape[axis], inner,
              float(tol), count.data_ptr())

@@ -117,14 +117,23 @@ class FlatBuffers:
                 p, slot = self.params[i], self.slots[i]
                 g = p.grad
                 if g is None:
-                    slot.zero_()
+                    if slot.is_cuda:
+                        from .ops import fill_zero
+                        fill_zero(slot)                # library launches: they are on the launch tape
+                    else:
+                        slot.zero_()
                 elif g.data_ptr() != slot.data_ptr():
-                    if slot.is_cuda and g.dtype == slot.dtype and g.shape == slot.shape:
-                        torch.mul(g, 1.0, out=slot)    # a kernel, not hipMemcpyDtoD (which can stall for 100s of us on a busy device)
+                    if slot.is_cuda and g.dtype == slot.dtype and g.shape == slot.shape and g.is_contiguous() and g.data_ptr() % 16 == 0:
+                        from ._cabi import call
+                        from .ops import _stream
+                        call("miseg_copy", _stream(), slot.data_ptr(), g.data_ptr(), slot.numel() * 4)   # a kernel, not hipMemcpyDtoD (which can stall for 100s of us on a busy device)
+                    elif slot.is_cuda and g.dtype == slot.dtype and g.shape == slot.shape:
+                        torch.mul(g, 1.0, out=slot)
                     else:
                         slot.copy_(g)
                     if g.is_cuda:
-                        g.record_stream(torch.cuda.current_stream(g.device))   # may be another stream than g's own (GradReducer._launch)
+                        from .tape import keep
+                        keep(g, torch.cuda.current_stream(g.device))   # may be another stream than g's own (GradReducer._launch)
                 else:
                     continue
                 p.grad = slot
@@ -202,6 +211,21 @@ class FusedAdam(torch.optim.Optimizer):
             self._pending_state = None
 
     @torch.no_grad()
+    def host_step(self) -> List[List[float]]:
+        """Host half of a step without any device traffic: bump the step counters and return, per parameter group, the four scalars
+        of the update (lr / bias correction 1, 1 / sqrt(bias correction 2), eps, weight decay).  The training loop stages them in the
+        iteration's step block (``stepio.StepIO.begin``), whose single upload carries them; ``apply(io=...)`` reads them there."""
+        rows = []
+        for gi, group in enumerate(self.param_groups):
+            self._ensure_state(gi)
+            self._steps[gi] += 1
+            t = self._steps[gi]
+            b1, b2 = group["betas"]
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            rows.append([group["lr"] / bc1, 1.0 / math.sqrt(bc2), group["eps"], group["weight_decay"]])
+        return rows
+
+    @torch.no_grad()
     def advance(self) -> None:
         """Host half of a step: bump the step counters and upload (lr / bias corrections, eps, weight decay) to the device
         hyper-parameter array.  Kept apart from ``apply`` so that a captured hipGraph of the step (semi_seg.epocher) can
@@ -228,10 +252,27 @@ class FusedAdam(torch.optim.Optimizer):
             ring.upload_into(lambda slot: slot.copy_(vals), self._hyper[gi])
 
     @torch.no_grad()
-    def apply(self, guard: Optional[Tensor] = None) -> None:
+    def apply(self, guard: Optional[Tensor] = None, io=None) -> None:
         """Device half: gather stray gradients into the flat buffer and launch the fused Adam kernel (a no-op on the device if any
-        of the fp32 flags in ``guard`` is set)."""
+        of the fp32 flags in ``guard`` is set).  ``io`` = the iteration's step block (``stepio.StepIO``): the update's scalars -- and
+        the loss scale of the half-precision mode -- are read from it on the device, and the overflow count lands in its read-back
+        block right behind the guard flags (one contiguous guard vector, no ``torch.cat``)."""
         self.last_nonfinite = None
+        if io is not None and (len(self.param_groups) == 1 or self.loss_scaler is None):
+            for gi, group in enumerate(self.param_groups):
+                fb = self._flats[gi]
+                b1, b2 = group["betas"]
+                fb.collect()
+                scale = 1.0
+                if self.loss_scaler is not None:
+                    bad = io.overflow_slot(guard)          # fp32[1] behind the flags (or on its own when nothing guards)
+                    unet_ops.count_nonfinite(fb.flat_grad, out=bad)
+                    self.last_nonfinite = bad
+                    guard = io.guard_with_overflow(guard, bad)
+                    scale = 0.0                            # 1 / loss scale is hyper[4] of the step block
+                unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], io.hyper(gi), b1, b2, scale, guard)
+            unet_ops.PACK_CACHE.invalidate()
+            return
         for gi, group in enumerate(self.param_groups):
             fb = self._flats[gi]
             b1, b2 = group["betas"]

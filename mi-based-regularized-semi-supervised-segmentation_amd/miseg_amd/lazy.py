@@ -84,13 +84,21 @@ class LinearLoss:
                 e[1] += c
         return [(t, c) for t, c in acc.values()]
 
-    def backward(self) -> None:
+    def backward(self, scale: float = 1.0) -> None:
+        """Seed autograd at the kernel outputs with constant gradients ``coefficient * scale`` (``scale`` = the loss scale of the fp16
+        storage mode).  Inside an iteration the constants live in the step block (``stepio.StepIO.seed``: refreshed by the iteration's
+        one upload with the CURRENT scale, so a dynamic loss scale needs no new tensors); otherwise cached ``torch.full`` tensors."""
+        from . import stepio
+        io = stepio.CURRENT
         roots, grads = [], []
         for t, c in self.merged():
             if t.requires_grad:
                 roots.append(t)
-                grads.append(_const(("g", tuple(t.shape), t.dtype, str(t.device), c),
-                                    lambda t=t, c=c: torch.full(t.shape, c, dtype=t.dtype, device=t.device)))
+                if io is not None and t.is_cuda and t.dtype == torch.float32 and io.device == t.device and io.scale == float(scale):
+                    grads.append(io.seed(t.shape, c))
+                else:
+                    grads.append(_const(("g", tuple(t.shape), t.dtype, str(t.device), c * scale),
+                                        lambda t=t, c=c: torch.full(t.shape, c * scale, dtype=t.dtype, device=t.device)))
         torch.autograd.backward(roots, grads)
 
     def detach(self) -> "LinearLoss":
@@ -158,6 +166,12 @@ def report(items: Sequence[Union[LinearLoss, Tensor]], check_items: Sequence[tup
         return evaluate(items, passthrough=[_checks.flag_tensor(c) for c in check_items])
     dev = tensors_all[0].device
     cur = torch.cuda.current_stream(dev)
+    from . import stepio
+    io = stepio.CURRENT
+    if io is not None and io.device == dev:
+        out = _report_in_place(io, items, srcs, _checks, cur)
+        if out is not None:
+            return out
     fl: List[Tensor] = []          # float tensors, in flat order
     off: Dict[int, int] = {}
     n_f = 0
@@ -204,3 +218,54 @@ def report(items: Sequence[Union[LinearLoss, Tensor]], check_items: Sequence[tup
         call("miseg_report_scalars", cur.cuda_stream, flat.data_ptr(), None if iflat is None else iflat.data_ptr(), coeff.data_ptr(),
              len(items), C, d_dev.data_ptr(), len(srcs), out.data_ptr())
     return out
+
+
+def _report_in_place(io, items, srcs, _checks, cur) -> "Tensor | None":
+    """``report`` when every value lives in the iteration's scalar arena and every integer flag in its counter block
+    (``stepio.StepIO.scalar`` / ``counter``: the loss kernels and the heads wrote them there): the kernel reads the arena in place
+    -- no ``torch.cat`` -- and writes into the iteration's read-back block.  One slot is left free behind the flags: the fp16 mode's
+    overflow count goes there, so that the optimiser's guard stays one contiguous vector.  None if anything lives elsewhere."""
+    from ._cabi import call
+    cols: List[Tuple[int, int]] = []
+    for it in items:
+        for t, _ in it.terms:
+            o = io.arena_offset(t)
+            if o is None:
+                return None
+            cols.append((o, t.numel()))
+    desc: List[int] = []
+    for s in srcs:
+        if isinstance(s, _checks.LazyFlag) and s.kind == "cast":
+            i = io.counter_index(s.tensor)
+            if i is None or s.tensor.numel() != 1:
+                return None
+            desc += [2, i, 0]
+        elif isinstance(s, _checks.LazyFlag):
+            o = io.arena_offset(s.tensor)
+            if o is None:
+                return None
+            desc += [1, o, s.tensor.numel()]
+        else:
+            o = io.arena_offset(s)
+            if o is None or s.numel() != 1:
+                return None
+            desc += [0, o, 1]
+    C = io._cursor_arena
+    dev = io.device
+    key = ("rep_io", str(dev), tuple(tuple((io.arena_offset(t), t.numel(), c) for t, c in it.terms) for it in items), C, tuple(desc))
+
+    def build():
+        m = torch.zeros(max(len(items), 1), max(C, 1), dtype=torch.float32)
+        for r, it in enumerate(items):
+            for t, c in it.terms:
+                o = io.arena_offset(t)
+                m[r, o:o + t.numel()] += c
+        d = torch.tensor(desc if desc else [0, 0, 0], dtype=torch.int32)
+        return m.to(dev), d.to(dev)
+    coeff, d_dev = _const(key, build)
+    n = len(items) + len(srcs)
+    out = io.out("scalars", (n + 1,), torch.float32)
+    io.last_report = out
+    call("miseg_report_scalars", cur.cuda_stream, io.arena.data_ptr(), io.counters_base().data_ptr(), coeff.data_ptr(), len(items), C,
+         d_dev.data_ptr(), len(srcs), out.data_ptr())
+    return out[:n]

@@ -12,8 +12,9 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from . import _cabi
+from . import _cabi, stepio
 from ._cabi import BF16, F16, F32, call, query
+from .tape import keep
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -55,6 +56,31 @@ def wait_stream(waiter: "torch.cuda.Stream", producer: "torch.cuda.Stream") -> N
         waiter.wait_stream(producer)
         return
     call("miseg_stream_wait_stream", waiter.cuda_stream, producer.cuda_stream)
+
+
+def scalar_out(shape, device) -> Tensor:
+    """fp32 tensor for a kernel's small result: inside an iteration it lives in the iteration's scalar arena (stepio), where the
+    report kernel reads it in place; otherwise an ordinary allocation."""
+    io = stepio.CURRENT
+    if io is not None and io.device == device:
+        return io.scalar(shape)
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
+def zero_counter(device, shape=()) -> Tensor:
+    """int32 counter that is zero before the kernel that adds to it runs: inside an iteration the step block's upload has zeroed it
+    (no fill launch); otherwise torch.zeros."""
+    io = stepio.CURRENT
+    if io is not None and io.device == device:
+        return io.counter().view(tuple(shape))
+    return torch.zeros(tuple(shape), dtype=torch.int32, device=device)
+
+
+def fill_zero(t: Tensor) -> Tensor:
+    """``t.zero_()`` as a library launch (dense tensors; it is on the launch tape)."""
+    assert t.is_cuda and (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last))
+    call("miseg_fill_zero", _stream(), t.data_ptr(), t.numel() * t.element_size())
+    return t
 
 
 def _ws(nbytes: int, device) -> Tensor:
@@ -213,7 +239,7 @@ class _LocalMI(torch.autograd.Function):
         t = 2 * pad + 1
         raw = torch.empty(p, t, t, k, k, dtype=torch.float32, device=dev)
         _local_fwd(x, y, mask, pad, windows, win, raw)
-        loss = torch.empty(p, dtype=torch.float32, device=dev)
+        loss = scalar_out((p,), dev)
         grad_raw = torch.empty_like(raw)
         _local_loss(raw, k, pad, p, lamda, loss, grad_raw)
         ctx.save_for_backward(x, y, mask, grad_raw, win)
@@ -267,7 +293,7 @@ class _LocalMIHeads(torch.autograd.Function):
         else:
             for i in range(s):
                 _local_fwd(probs[i, :ub], probs[i, ub:], mask, pad, windows, win, raw[i])
-        loss = torch.empty(s, p, dtype=torch.float32, device=dev)
+        loss = scalar_out((s, p), dev)
         grad_raw = torch.empty_like(raw)
         _local_loss(raw, k, pad, s * p, lamda, loss, grad_raw)
         ctx.save_for_backward(probs, mask, grad_raw, win)
@@ -279,7 +305,9 @@ class _LocalMIHeads(torch.autograd.Function):
         probs, mask, grad_raw, win = ctx.saved_tensors
         s, _, k, h, w = probs.shape
         ub = ctx.ub
-        gprob = torch.empty_like(probs) if _is_whole(ctx.windows, h, w) else torch.zeros_like(probs)
+        gprob = torch.empty_like(probs)
+        if not _is_whole(ctx.windows, h, w):
+            fill_zero(gprob)
         scale = gloss.contiguous().float()
         if mask is None:
             whole = _is_whole(ctx.windows, h, w)
@@ -335,17 +363,20 @@ class _GlobalMI(torch.autograd.Function):
         _need_gpu(x, y)
         x, y = x.contiguous().float(), y.contiguous().float()
         s, n, k = x.shape
-        loss = torch.empty(s, dtype=torch.float32, device=x.device)
+        loss = scalar_out((s,), x.device)
         loss_nl = torch.empty_like(loss)
         joint = torch.empty(s, k, k, dtype=torch.float32, device=x.device)
         call("miseg_iic_global_fwd", _stream(), _ptr(x), _ptr(y), s, n, k, float(lamb), _ptr(loss), _ptr(loss_nl), _ptr(joint))
         ctx.save_for_backward(x, y)
         ctx.lamb = float(lamb)
         ctx.mark_non_differentiable(loss_nl, joint)
+        ctx.set_materialize_grads(False)      # (autograd would fill zero gradients for the two non-differentiable outputs: two launches)
         return loss, loss_nl, joint
 
     @staticmethod
     def backward(ctx, gloss, _g1, _g2):
+        if gloss is None:
+            return None, None, None
         x, y = ctx.saved_tensors
         s, n, k = x.shape
         gx, gy = torch.empty_like(x), torch.empty_like(y)
@@ -410,17 +441,20 @@ class _GlobalMIPair(torch.autograd.Function):
         prob = prob.contiguous().float()
         s, n2, k = prob.shape
         n = n2 // 2
-        loss = torch.empty(s, dtype=torch.float32, device=prob.device)
+        loss = scalar_out((s,), prob.device)
         loss_nl = torch.empty_like(loss)
         joint = torch.empty(s, k, k, dtype=torch.float32, device=prob.device)
         call("miseg_iic_global_fwd_pair", _stream(), _ptr(prob), s, n, k, float(lamb), _ptr(loss), _ptr(loss_nl), _ptr(joint))
         ctx.save_for_backward(prob)
         ctx.lamb = float(lamb)
         ctx.mark_non_differentiable(loss_nl, joint)
+        ctx.set_materialize_grads(False)      # (autograd would fill zero gradients for the two non-differentiable outputs: two launches)
         return loss, loss_nl, joint
 
     @staticmethod
     def backward(ctx, gloss, _g1, _g2):
+        if gloss is None:
+            return None, None
         prob, = ctx.saved_tensors
         s, n2, k = prob.shape
         gprob = torch.empty_like(prob)
@@ -500,8 +534,9 @@ class _LocalHead(torch.autograd.Function):
         ctx.stack_params = (getattr(w, "_miseg_stack_params", None), getattr(b, "_miseg_stack_params", None))
         w, b = w.contiguous().float(), b.contiguous().float()
         prob = torch.empty(s, m, k, h, wd, dtype=torch.float32, device=feat.device)
-        viol = torch.zeros((), dtype=torch.int32, device=feat.device) if k <= 32 else None
+        viol = zero_counter(feat.device) if k <= 32 else None
         _LocalHead.last_violations = viol
+        ctx.sink = getattr(feat, "_miseg_grad_sink", None)
         call("miseg_head_local_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), _ptr(b),
              s, k, float(temperature), _ptr(prob), 2e-4, _ptr(viol), work=(2.0 * s * k * c * m * h * wd, (s * k * 4.0 + c * feat.element_size()) * m * h * wd),
              tag=f"head_local_fwd[c{c}]")
@@ -539,24 +574,41 @@ class _LocalHead(torch.autograd.Function):
                 done.record(cur)
                 writer.wait_event(done)       # whoever reads the joined gradient next does so on the writer's stream
             return None, gw, gb, None, None, None
+        sink = ctx.sink if not _GradJoin.enabled else None
+        compact, n0, n1 = False, 0, bsz
         if ctx.needs_input_grad[0]:
             rng = ctx.src_range
             if rng is not None and feat.dtype in (torch.bfloat16, torch.float16) and k == 20 and s == 5 and c in (16, 32) and 0 <= rng[0] <= rng[1] <= bsz:
-                # the shipped kernels store (not accumulate) every pixel and channel of the rows in src = [start, stop): only the
-                # other rows need the zero fill (a third of the 100 MB at the bench shape, on the step's critical path)
-                gfeat = torch.empty((bsz, c, h, wd), dtype=feat.dtype, device=feat.device, memory_format=torch.channels_last)
-                if rng[0] > 0:
-                    gfeat[:rng[0]].zero_()
-                if rng[1] < bsz:
-                    gfeat[rng[1]:].zero_()
+                # the shipped kernels store (not accumulate) every pixel and channel of the rows in src = [start, stop) and touch no other
+                if sink is not None and rng[0] < rng[1]:
+                    # ... so a COMPACT gradient of those rows is all there is: the producing layer's BatchNorm backward adds it in its
+                    # loaders (unet_ops._GradSink) -- no zero fill of the other rows, no add kernel over the whole batch
+                    n0, n1 = rng
+                    gfeat = torch.empty((n1 - n0, c, h, wd), dtype=feat.dtype, device=feat.device, memory_format=torch.channels_last)
+                    compact = True
+                else:
+                    gfeat = torch.empty((bsz, c, h, wd), dtype=feat.dtype, device=feat.device, memory_format=torch.channels_last)
+                    if rng[0] > 0:
+                        fill_zero(gfeat[:rng[0]])
+                    if rng[1] < bsz:
+                        fill_zero(gfeat[rng[1]:])
             else:
-                gfeat = zeros_nhwc(bsz, c, h, wd, feat.dtype, feat.device)
+                gfeat = fill_zero(empty_nhwc(bsz, c, h, wd, feat.dtype, feat.device))
         gw = _stacked_grad(ctx.stack_params[0], w.shape, feat.device)
         gb = _stacked_grad(ctx.stack_params[1], (s, k), feat.device)
         ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
-        call("miseg_head_local_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
-             ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
-             work=(4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 2 * c * feat.element_size()) * m * h * wd), tag=f"head_local_bwd[c{c}]")
+        work = (4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 2 * c * feat.element_size()) * m * h * wd)
+        if compact:
+            call("miseg_head_local_bwd_rows", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
+                 ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), n0, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), work=work,
+                 tag=f"head_local_bwd[c{c}]")
+        else:
+            call("miseg_head_local_bwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
+                 ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), work=work,
+                 tag=f"head_local_bwd[c{c}]")
+        if gfeat is not None and sink is not None:
+            sink.put(gfeat, n0, n1)          # handed to the producing layer's backward; autograd gets no gradient from this edge
+            return None, gw, gb, None, None, None
         if gfeat is not None:
             _GradJoin.offer(feat, gfeat)     # a later consumer of the same feature (e.g. up_conv's pooled data gradient) may add into it
         return gfeat, gw, gb, None, None, None
@@ -592,6 +644,8 @@ class _GlobalHead(torch.autograd.Function):
              float(temperature), _ptr(pooled), _ptr(prob))
         ctx.save_for_backward(w, src, pooled, prob)
         ctx.meta = (bsz, c, h, wd, feat.dtype, float(temperature))
+        ctx.sink = getattr(feat, "_miseg_grad_sink", None)
+        ctx.src_range = getattr(src, "_miseg_range", None)
         return prob
 
     @staticmethod
@@ -601,12 +655,28 @@ class _GlobalHead(torch.autograd.Function):
         s, k, _ = w.shape
         m = src.numel()
         gprob = gprob.contiguous().float()
-        gfeat = zeros_nhwc(bsz, c, h, wd, dtype, w.device) if ctx.needs_input_grad[0] else None
+        gfeat, compact, n0, n1 = None, False, 0, bsz
+        sink, rng = ctx.sink, ctx.src_range
+        if ctx.needs_input_grad[0]:
+            if sink is not None and rng is not None and 0 <= rng[0] < rng[1] <= bsz and rng[1] - rng[0] == m:
+                # the kernel writes every element of the rows in src = [start, stop) and nothing else: a compact gradient (_LocalHead)
+                n0, n1 = rng
+                gfeat = empty_nhwc(n1 - n0, c, h, wd, dtype, w.device)
+                compact = True
+            else:
+                gfeat = fill_zero(empty_nhwc(bsz, c, h, wd, dtype, w.device))
         gw = _stacked_grad(ctx.stack_params[0], w.shape, w.device)
         gb = _stacked_grad(ctx.stack_params[1], (s, k), w.device)
         dz = torch.empty(s * m * k, dtype=torch.float32, device=w.device)
-        call("miseg_head_global_bwd", _stream(), _DT[dtype], bsz, h, wd, c, _ptr(src), m, _ptr(w), s, k, temperature, _ptr(pooled),
-             _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(dz))
+        if compact:
+            call("miseg_head_global_bwd_rows", _stream(), _DT[dtype], bsz, h, wd, c, _ptr(src), m, _ptr(w), s, k, temperature, _ptr(pooled),
+                 _ptr(prob), _ptr(gprob), _ptr(gfeat), n0, _ptr(gw), _ptr(gb), _ptr(dz))
+        else:
+            call("miseg_head_global_bwd", _stream(), _DT[dtype], bsz, h, wd, c, _ptr(src), m, _ptr(w), s, k, temperature, _ptr(pooled),
+                 _ptr(prob), _ptr(gprob), _ptr(gfeat), _ptr(gw), _ptr(gb), _ptr(dz))
+        if gfeat is not None and sink is not None:
+            sink.put(gfeat, n0, n1)
+            return None, gw, gb, None, None
         return gfeat, gw, gb, None, None
 
 
@@ -720,26 +790,28 @@ class _SoftmaxKL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, labels: Tensor):
         _need_gpu(logits, labels)
+        raw_logits = logits
         logits = _logits_nhwc(logits)
         n, c, h, w = logits.shape
         labels = labels.contiguous().view(n, h, w)
         if labels.dtype != torch.int64:
             labels = labels.long()
         dev = logits.device
-        loss = torch.empty((), dtype=torch.float32, device=dev)
+        loss = scalar_out((), dev)
         glogits = empty_nhwc(n, c, h, w, torch.float32, dev)
-        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        bad = zero_counter(dev, (1,))
         ws = _ws(query("miseg_loss_ws_bytes", n, h, w), dev)
         call("miseg_softmax_kl", _stream(), _ptr(logits), _ptr(labels), n, h, w, c, None, _ptr(loss), _ptr(glogits), _ptr(bad),
              _ptr(ws), ws.numel())
         ctx.save_for_backward(glogits)
         ctx.bad = bad
+        ctx.part = _split_part_of(raw_logits, logits)
         return loss
 
     @staticmethod
     def backward(ctx, g: Tensor):
         (glogits,) = ctx.saved_tensors
-        return glogits * g, None
+        return _scaled_grad(ctx.part, glogits, g), None
 
 
 def softmax_kl(logits: Tensor, labels: Tensor, check_labels: bool = True) -> Tensor:
@@ -753,20 +825,22 @@ class _SoftmaxMSE(torch.autograd.Function):
     @classmethod
     def forward(cls, ctx, a: Tensor, b: Tensor, flips: Optional[Tensor]):
         _need_gpu(a, b, flips)
+        raw_a = a
         a, b = _logits_nhwc(a), _logits_nhwc(b.detach())
         n, c, h, w = a.shape
         dev = a.device
-        loss = torch.empty((), dtype=torch.float32, device=dev)
+        loss = scalar_out((), dev)
         ga = empty_nhwc(n, c, h, w, torch.float32, dev)
         ws = _ws(query("miseg_loss_ws_bytes", n, h, w), dev)
         call(cls.entry, _stream(), _ptr(a), _ptr(b), _ptr(flips), n, h, w, c, None, _ptr(loss), _ptr(ga), _ptr(ws), ws.numel())
         ctx.save_for_backward(ga)
+        ctx.part = _split_part_of(raw_a, a)
         return loss
 
     @staticmethod
     def backward(ctx, g: Tensor):
         (ga,) = ctx.saved_tensors
-        return ga * g, None, None
+        return _scaled_grad(ctx.part, ga, g), None, None
 
 
 def softmax_mse(a: Tensor, b: Tensor, flips: Optional[Tensor] = None) -> Tensor:
@@ -812,8 +886,9 @@ def flip(x: Tensor, flips: Tensor) -> Tensor:
     return _Flip.apply(x, flips) if x.requires_grad else _flip_raw(x, flips)
 
 
-def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True):
-    """argmax over channels and per-sample per-class (intersection, union) int64 counts."""
+def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True, to_host: bool = False):
+    """argmax over channels and per-sample per-class (intersection, union) int64 counts.  ``to_host``: inside a training iteration,
+    write the counts into the iteration's read-back block (``stepio``) so that they travel with its scalars."""
     _need_gpu(logits, labels)
     logits = _logits_nhwc(logits)
     n, c, h, w = logits.shape
@@ -822,8 +897,12 @@ def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True
     inter = uni = None
     if labels is not None:
         labels = labels.contiguous().view(n, h, w).long()
-        inter = torch.empty(n, c, dtype=torch.int64, device=dev)
-        uni = torch.empty(n, c, dtype=torch.int64, device=dev)
+        io = stepio.CURRENT if to_host else None
+        if io is not None and io.device == dev:          # the iteration's one device -> host copy carries them
+            inter, uni = io.out("inter", (n, c), torch.int64), io.out("union", (n, c), torch.int64)
+        else:
+            inter = torch.empty(n, c, dtype=torch.int64, device=dev)
+            uni = torch.empty(n, c, dtype=torch.int64, device=dev)
     call("miseg_argmax_dice", _stream(), _ptr(logits), _ptr(labels), n, h, w, c, _ptr(pred), _ptr(inter), _ptr(uni))
     return pred, inter, uni
 
@@ -832,16 +911,57 @@ def argmax_dice(logits: Tensor, labels: Optional[Tensor], want_pred: bool = True
 _SPLIT_MEMCPY = False   # True: assemble slice gradients with hipMemcpy (slower on a busy device)
 
 
+class _SplitHolder:
+    """Shared by the parts of one ``split_rows``: the batch gradient buffer that the split's backward returns.  A loss kernel whose
+    input IS a part writes its scaled gradient straight into that part's rows (``_scaled_grad``: one launch, where autograd would
+    multiply into a temporary and the split's backward would copy it over); the backward then only zero-fills the parts without a loss."""
+    __slots__ = ("meta", "sizes", "out")
+
+    def __init__(self, x: Tensor, sizes):
+        cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+        self.meta, self.sizes, self.out = (tuple(x.shape), x.dtype, x.device, cl), list(sizes), None
+
+    def buffer(self) -> Tensor:
+        if self.out is None:
+            shape, dtype, device, cl = self.meta
+            self.out = torch.empty(shape, dtype=dtype, device=device, memory_format=torch.channels_last if cl else torch.contiguous_format)
+        return self.out
+
+    def rows(self, idx: int) -> Tensor:
+        return self.buffer().narrow(0, sum(self.sizes[:idx]), self.sizes[idx])
+
+
+def _split_part_of(given: Tensor, used: Tensor):
+    """(holder, index) if ``used`` -- the tensor the kernel read -- is, unconverted, a part of a split_rows."""
+    tag = getattr(given, "_miseg_split", None)
+    if tag is None or used.data_ptr() != given.data_ptr() or used.dtype != torch.float32:
+        return None
+    return tag
+
+
+def _scaled_grad(part, grad: Tensor, g: Tensor) -> Tensor:
+    """``grad * g`` for a 0-d upstream gradient ``g``; for a part of a split_rows, written into the part's rows of the batch
+    gradient by one library launch (scale read from device memory) and returned as that view."""
+    if part is not None and g.dim() == 0 and g.dtype == torch.float32 and g.is_cuda and grad.dtype == torch.float32 and grad.numel() % 4 == 0:
+        holder, idx = part
+        dst = holder.rows(idx)
+        if dst.dtype == grad.dtype and dst.shape == grad.shape and dst.stride() == grad.stride():
+            call("miseg_assemble_rows", _stream(), _ptr(dst), _ptr(grad), _ptr(g), grad.numel(), None, None, 0, None, None, 0)
+            return dst
+    return grad * g
+
+
 class _SplitRows(torch.autograd.Function):
     """``torch.split(x, sizes, dim=0)`` whose backward assembles the gradient directly in x's memory format.
 
     The logits leave the network as one NHWC batch [labeled | unlabeled | flipped unlabeled] and are split for the losses
     (ref semi_seg/epocher.py:150-152).  Autograd's own split backward concatenates the per-part gradients, and a part without a
     loss (the detached UDA branch) arrives as NCHW zeros: the concatenation then comes out NCHW and the next kernel's NHWC view
-    of it is a 4-channel transposing copy -- measured 1.35 ms per step for 50 MB.  Here: one NHWC buffer, per-part dense copies."""
+    of it is a 4-channel transposing copy -- measured 1.35 ms per step for 50 MB.  Here: one NHWC buffer; parts whose loss kernel
+    wrote its rows already (``_scaled_grad``) cost nothing, absent parts are zero-filled, anything else is copied in."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, *sizes: int):
+    def forward(ctx, x: Tensor, holder, *sizes: int):
         ctx.sizes = sizes
         ctx.set_materialize_grads(False)    # a part without a loss stays None (materialised it would be NCHW zeros: a transposing copy)
         ctx.meta = (x.shape, x.dtype, x.device, x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
@@ -849,25 +969,50 @@ class _SplitRows(torch.autograd.Function):
         for n in sizes:
             outs.append(x.narrow(0, o, n))
             o += n
+        ctx.holder = holder
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         shape, dtype, device, cl = ctx.meta
-        out = torch.empty(shape, dtype=dtype, device=device, memory_format=torch.channels_last if cl else torch.contiguous_format)
+        holder = ctx.holder
+        if holder is not None:
+            out, holder.out = holder.buffer(), None
+        else:
+            out = torch.empty(shape, dtype=dtype, device=device, memory_format=torch.channels_last if cl else torch.contiguous_format)
         o = 0
         for n, g in zip(ctx.sizes, grads):
             part = out.narrow(0, o, n)
             if g is None:
-                part.zero_()
-            else:
-                if _SPLIT_MEMCPY:
-                    part.copy_(g)
+                if part.is_cuda and n:
+                    fill_zero(part)
                 else:
-                    torch.mul(g, 1.0, out=part)   # an elementwise kernel: copy_ of two dense tensors is a hipMemcpyDtoD, seen at 1.5 ms for 16 MB
+                    part.zero_()
+            elif g.data_ptr() == part.data_ptr() and g.shape == part.shape and g.stride() == part.stride():
+                pass                              # its loss kernel's backward wrote these rows (_scaled_grad)
+            elif _SPLIT_MEMCPY:
+                part.copy_(g)
+            else:
+                torch.mul(g, 1.0, out=part)   # an elementwise kernel: copy_ of two dense tensors is a hipMemcpyDtoD, seen at 1.5 ms for 16 MB
             o += n
-        return (out,) + (None,) * len(ctx.sizes)
+        return (out,) + (None,) * (len(ctx.sizes) + 1)
 
 
 def split_rows(x: Tensor, sizes) -> tuple:
-    return _SplitRows.apply(x, *[int(n) for n in sizes])
+    holder = _SplitHolder(x, [int(n) for n in sizes]) if x.is_cuda and x.requires_grad else None
+    outs = _SplitRows.apply(x, holder, *[int(n) for n in sizes])
+    if holder is not None:
+        for i, t in enumerate(outs):
+            t._miseg_split = (holder, i)
+    return outs
+
+
+def cat_flip(a: Tensor, b: Tensor, flips: Tensor) -> Tensor:
+    """``torch.cat([a, b, flip(b)])`` along dim 0 in one launch (ref semi_seg/epocher.py:148-153: the network's input batch)."""
+    _need_gpu(a, b, flips)
+    a, b = a.contiguous(), b.contiguous()
+    assert a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and a.element_size() == 4 and a.dim() == 4, (a.shape, b.shape, a.dtype)
+    na, nb = a.shape[0], b.shape[0]
+    out = torch.empty((na + 2 * nb,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    call("miseg_cat_flip", _stream(), _ptr(a), na, _ptr(b), nb, a.shape[1], a.shape[2], a.shape[3], _ptr(flips), _ptr(out))
+    return out

@@ -20,6 +20,7 @@ from torch import Tensor
 from ._cabi import call, query
 from .gradslot import grad_slot
 from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc, wait_stream
+from .tape import keep
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
@@ -77,6 +78,26 @@ class _BnRec:
         return (parts, nparts) if mine and parts is not None else (None, 0)
 
 
+class _GradSink:
+    """Side channel for a SECOND gradient of a layer's activation.  A tapped feature map feeds the next layer and a cluster head (ref
+    semi_seg/epocher.py:258-273, the head sees the last 2 UB samples); autograd would add the two gradients with an elementwise kernel
+    over the whole batch, behind a zero fill of the samples the head does not touch.  Instead the head's backward ``put``s its compact
+    gradient (samples [n0, n1) only) here and returns no gradient; this layer's backward -- which autograd runs after every consumer
+    of the activation, whatever they return -- ``take``s it and the BatchNorm-backward kernels add it in their loaders
+    (``miseg_bn_relu_bwd_dual``)."""
+    __slots__ = ("items",)
+
+    def __init__(self):
+        self.items = []
+
+    def put(self, grad: Tensor, n0: int, n1: int) -> None:
+        self.items.append((grad, int(n0), int(n1), torch.cuda.current_stream(grad.device)))
+
+    def take(self):
+        items, self.items = self.items, []
+        return items
+
+
 class _SyncCounters:
     """int32 counters for the "last block finishes" launches (miseg_conv3x3_bn_fwd, miseg_bn_relu_bwd_sync): zero when a launch
     starts, zero again when it ends.  One zero-filled array per device, handed out round-robin, so that launches which could overlap
@@ -131,10 +152,16 @@ def stem_input(image: Tensor, dtype) -> Tensor:
     return out
 
 
-def _pack_now(weight: Tensor, dtype, kind: int, ci_begin: int, ci_count: int, packed: Optional[Tensor] = None) -> Tensor:
-    cout, cin = weight.shape[0], weight.shape[1]
+def _pack_now(weight: Tensor, dtype, kind: int, ci_begin: int, ci_count: int, packed: Optional[Tensor] = None, cin: Optional[int] = None) -> Tensor:
+    cout, cin_w = weight.shape[0], weight.shape[1]
+    kind &= 0xff
+    if cin is not None and cin != cin_w:      # forward layout of a weight with fewer input channels than the (padded) activation
+        assert kind == 0 and cin > cin_w, (kind, cin, cin_w)
+        kind, ci_count = cin_w << 8, cin
+    else:
+        cin = cin_w
     if packed is None:
-        packed = torch.empty((ci_count if kind else cout) * (cout if kind else cin) * 9, dtype=dtype, device=weight.device)
+        packed = torch.empty((ci_count if kind & 0xff else cout) * (cout if kind & 0xff else cin) * 9, dtype=dtype, device=weight.device)
     call("miseg_pack_conv3x3_weights", _stream(), _DT[dtype], _ptr(weight), cout, cin, kind, ci_begin, ci_count, _ptr(packed))
     return packed
 
@@ -157,25 +184,29 @@ class _PackCache:
         self.packed_epoch = -1
         self.jobs_dev = {}        # dtype -> (device job table, njobs, total_blocks, keys)
         self.dirty = True
+        self.generation = 0       # bumped whenever the set of packed tensors (hence the addresses a launch tape recorded) changes
 
     def invalidate(self) -> None:
         self.epoch += 1
 
-    def get(self, weight: Tensor, dtype, kind: int, cb: int, cs: int) -> Tensor:
+    def get(self, weight: Tensor, dtype, kind: int, cb: int, cs: int, cin: Optional[int] = None) -> Tensor:
+        """``cin`` (forward layout only): input channels of the PACKED tensor when the weight has fewer (the stem); the kind word then
+        carries the weight's own count in its high bits (miseg_pack_conv3x3_weights)."""
         if getattr(weight, "_miseg_grad_slot", None) is None or not weight.is_cuda or _NO_PACK_CACHE:
-            return _pack_now(weight, dtype, kind, cb, cs)
+            return _pack_now(weight, dtype, kind, cb, cs, cin=cin)
         key = (weight.data_ptr(), tuple(weight.shape), dtype, kind, cb, cs)
         ent = self.entries.get(key)
         if ent is None or ent[0]() is not weight:
             # entry: [weakref(weight), dtype, kind, cb, cs, packed, version packed at, epoch packed at]
-            ent = self.entries[key] = [weakref.ref(weight), dtype, kind, cb, cs, _pack_now(weight, dtype, kind, cb, cs),
+            ent = self.entries[key] = [weakref.ref(weight), dtype, kind, cb, cs, _pack_now(weight, dtype, kind, cb, cs, cin=cin),
                                        weight._version, self.epoch]
             self.dirty = True
+            self.generation += 1
             return ent[5]
         if self.packed_epoch != self.epoch:
             self._repack_all()
         if ent[6] != weight._version or ent[7] != self.epoch:   # edited in place since / registered after the batch
-            _pack_now(weight, dtype, kind, cb, cs, ent[5])
+            _pack_now(weight, dtype, kind, cb, cs, ent[5], cin=cin)
             ent[6], ent[7] = weight._version, self.epoch
         return ent[5]
 
@@ -187,7 +218,7 @@ class _PackCache:
             # the job table would need a host->device copy, which a capturing stream does not allow: pack one by one
             for ent in self.entries.values():
                 w = ent[0]()
-                _pack_now(w, ent[1], ent[2], ent[3], ent[4], ent[5])
+                _pack_now(w, ent[1], ent[2] & 0xff, ent[3], ent[4], ent[5], cin=(ent[4] if ent[2] >> 8 else None))
                 ent[6], ent[7] = w._version, self.epoch
             self.packed_epoch = self.epoch
             return
@@ -200,7 +231,8 @@ class _PackCache:
                 blob, first = bytearray(), 0
                 for ent in ents:
                     w, packed = ent[0](), ent[5]
-                    blob += struct.pack("<QQiiiiii", w.data_ptr(), packed.data_ptr(), w.shape[0], w.shape[1], ent[2], ent[3], ent[4], first)
+                    cin_packed = ent[4] if ent[2] >> 8 else w.shape[1]      # stem: packed with more input channels than the weight has
+                    blob += struct.pack("<QQiiiiii", w.data_ptr(), packed.data_ptr(), w.shape[0], cin_packed, ent[2], ent[3], ent[4], first)
                     first += (packed.numel() + 255) // 256
                 table = torch.frombuffer(blob, dtype=torch.uint8).clone().to(ents[0][5].device)
                 self.jobs_dev[dtype] = (table, len(ents), first, ents)
@@ -216,9 +248,11 @@ class _PackCache:
 PACK_CACHE = _PackCache()
 
 
-def _pack(weight: Tensor, dtype, kind: int, ci_begin: int = 0, ci_count: int = 0) -> Tensor:
+def _pack(weight: Tensor, dtype, kind: int, ci_begin: int = 0, ci_count: int = 0, cin: Optional[int] = None) -> Tensor:
     if not kind:
         ci_begin, ci_count = 0, weight.shape[1]
+        if cin is not None and cin != weight.shape[1]:
+            return PACK_CACHE.get(weight, dtype, weight.shape[1] << 8, 0, int(cin), cin=int(cin))
     return PACK_CACHE.get(weight, dtype, kind, int(ci_begin), int(ci_count))
 
 
@@ -226,7 +260,7 @@ class _ConvBNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor,
                 running_var: Tensor, nbt: Tensor, training: bool, ups0: int, ups1: int, want_pool: bool, rec: Optional[_BnRec] = None,
-                rec0: Optional[_BnRec] = None, rec1: Optional[_BnRec] = None):
+                rec0: Optional[_BnRec] = None, rec1: Optional[_BnRec] = None, sink: Optional[_GradSink] = None):
         _need_gpu(x0, x1, weight)
         x0 = as_nhwc(x0)
         dtype, dev = x0.dtype, x0.device
@@ -238,9 +272,10 @@ class _ConvBNReLU(torch.autograd.Function):
             c1 = x1.shape[1]
             assert x1.dtype == dtype and (x1.shape[2] << ups1, x1.shape[3] << ups1) == (h, w)
         cout = weight.shape[0]
-        assert weight.shape[1] == c0 + c1, (weight.shape, c0, c1)
+        # the stem: one image channel read as a whole (zero-padded) channel vector; the weight keeps its own shape, the pack kernel pads
+        assert weight.shape[1] == c0 + c1 or (x1 is None and weight.shape[1] < c0), (weight.shape, c0, c1)
         weight = weight.contiguous().float()
-        packed = _pack(weight, dtype, 0)
+        packed = _pack(weight, dtype, 0, cin=c0 + c1)
         raw = empty_nhwc(n, cout, h, w, dtype, dev)
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         if training:
@@ -273,6 +308,7 @@ class _ConvBNReLU(torch.autograd.Function):
         if rec is not None:
             rec.raw, rec.saved, rec.shape = raw, saved, (n, cout, h, w)
         ctx.recs = (rec, rec0, rec1)
+        ctx.sink = sink
         if want_pool:
             return y, pooled
         return y, None
@@ -282,8 +318,20 @@ class _ConvBNReLU(torch.autograd.Function):
         x0, x1, weight, gamma, raw, y, saved = ctx.saved_tensors
         training, ups0, ups1, want_pool, c0, c1, n, h, w, cout = ctx.cfg
         dtype, dev = raw.dtype, raw.device
-        if gy is None and gpool is None:
-            return (None,) * 15
+        extras = ctx.sink.take() if ctx.sink is not None else []
+        if gy is None and gpool is None and not extras:
+            return (None,) * 16
+        cur = torch.cuda.current_stream(dev)
+        for g2, _, _, st2 in extras:
+            wait_stream(cur, st2)             # (autograd would have made the same wait before adding the two gradients)
+            keep(g2, cur)
+        extra = None
+        if len(extras) == 1 and (gy is not None or gpool is not None) and extras[0][0].dtype == dtype:
+            extra = extras[0]
+        elif extras:                          # several heads on one tap, or a tap nothing else consumes: add them here, in torch
+            gy = gy.clone() if gy is not None else torch.zeros((n, cout, h, w), dtype=dtype, device=dev, memory_format=torch.channels_last)
+            for g2, a, b, _ in extras:
+                gy[a:b] += g2.to(dtype)
         rec, rec0, rec1 = ctx.recs
         ext_parts, ext_nparts = rec.take(gy) if rec is not None else (None, 0)
         if _FUSE_BN_BWD and not want_pool and gpool is None and gy is not None and _dgrads_fusable(ctx, dtype):
@@ -298,9 +346,16 @@ class _ConvBNReLU(torch.autograd.Function):
         if gbeta is None:
             gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
-        call("miseg_bn_relu_bwd_sync", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
-             int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(), _ptr(SYNC_COUNTERS.take(dev)),
-             work=(0.0, float(raw.element_size()) * n * h * w * cout * 5.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
+        if extra is not None:
+            g2, n0, n1, _ = extra
+            g2 = as_nhwc(g2)
+            call("miseg_bn_relu_bwd_dual", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), _ptr(gpool), _ptr(g2), n0, n1, n, h, w, cout, _ptr(gamma),
+                 _ptr(saved), int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(),
+                 work=(0.0, float(raw.element_size()) * n * h * w * cout * 5.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
+        else:
+            call("miseg_bn_relu_bwd_sync", _stream(), _DT[dtype], _ptr(raw), _ptr(y), _ptr(gy), _ptr(gpool), n, h, w, cout, _ptr(gamma), _ptr(saved),
+                 int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(), _ptr(SYNC_COUNTERS.take(dev)),
+                 work=(0.0, float(raw.element_size()) * n * h * w * cout * 5.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
         gw = None
         if ctx.needs_input_grad[2]:
             gw = grad_slot(pw)
@@ -317,19 +372,25 @@ class _ConvBNReLU(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
                 wait_stream(side, cur)        # graw is produced above
                 for t in (graw, x0, x1):      # keep their memory from being recycled under the side stream
-                    if t is not None:
-                        t.record_stream(side)
+                    keep(t, side)
                 _wgrad_dirty.add(dev)
             # launched on the side stream by HANDLE (entering the `torch.cuda.stream` context costs 15-20 us of host time, 22 times per
             # backward pass); the workspace comes from the current stream's pool and is handed to the side stream like the operands
             ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
+            # the stem's weight has fewer input channels than the channel vector its activation was padded to: the kernel computes the
+            # padded gradient, a slice of it is the parameter's
+            gw_full = gw if weight.shape[1] == c0 + c1 else torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dev)
             if side is not None:
-                ws2.record_stream(side)
+                keep(ws2, side)
+                if gw_full is not gw:
+                    keep(gw_full, side)
 
             def launch(stream_handle):
-                call("miseg_conv3x3_wgrad", stream_handle, _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw),
+                call("miseg_conv3x3_wgrad", stream_handle, _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw_full),
                      _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
                      tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
+                if gw_full is not gw:
+                    call("miseg_conv3x3_wgrad_slice", stream_handle, _ptr(gw_full), cout, c0 + c1, weight.shape[1], _ptr(gw))
             from . import _cabi
             if side is None:
                 launch(_stream())
@@ -348,7 +409,7 @@ class _ConvBNReLU(torch.autograd.Function):
             call("miseg_conv3x3_dgrad_dual", _stream(), _DT[dtype], _ptr(graw), cout, n, h, w, _ptr(packed), c0, _ptr(g0), c1, _ptr(g1),
                  work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
                  tag=f"conv3x3_dgrad[{h}x{w},{cout}->{c0}+{c1}]")
-            return g0, g1, gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
+            return g0, g1, gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None, None
         for s, (cb, cs, ups, xs) in enumerate(((0, c0, ups0, x0), (c0, c1, ups1, x1))):
             if xs is None or not ctx.needs_input_grad[s]:
                 continue
@@ -398,7 +459,7 @@ class _ConvBNReLU(torch.autograd.Function):
                 call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)
                 gfull = glow
             grads[s] = gfull
-        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
+        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _backward_fused(ctx, gy_in: Tensor, ext_parts: Optional[Tensor], ext_nparts: int):
@@ -436,8 +497,7 @@ class _ConvBNReLU(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
                 wait_stream(side, cur)        # coef is produced above
                 for t in (raw, gy, coef, x0, x1):
-                    if t is not None:
-                        t.record_stream(side)
+                    keep(t, side)
                 _wgrad_dirty.add(dev)
             with torch.cuda.stream(side if side is not None else cur):
                 ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
@@ -473,7 +533,7 @@ class _ConvBNReLU(torch.autograd.Function):
                 call("miseg_sumpool2x2", _stream(), _DT[dtype], _ptr(gfull), n, h, w, cs, _ptr(glow), 0)
                 gfull = glow
             grads[s] = gfull
-        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None
+        return grads[0], grads[1], gw, ggamma, gbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _dgrads_fusable(ctx, dtype) -> bool:
@@ -504,10 +564,13 @@ def conv_bn_relu(x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor
     rec = _BnRec() if (_FUSE_BN_BWD and _FUSE_BN_RED and not want_pool and torch.is_grad_enabled()) else None
     rec0 = getattr(x0, "_miseg_bn", None) if not ups0 else None
     rec1 = getattr(x1, "_miseg_bn", None) if x1 is not None and not ups1 else None
+    sink = _GradSink() if torch.is_grad_enabled() and not _FUSE_BN_BWD else None
     y, pooled = _ConvBNReLU.apply(x0, x1, weight, gamma, beta, running_mean, running_var, nbt, bool(training), int(ups0), int(ups1),
-                                  bool(want_pool), rec, rec0, rec1)
+                                  bool(want_pool), rec, rec0, rec1, sink)
     if rec is not None and rec.raw is not None:
         y._miseg_bn = rec
+    if sink is not None and y.requires_grad:
+        y._miseg_grad_sink = sink
     return y, pooled
 
 
@@ -526,6 +589,7 @@ class _Conv1x1(torch.autograd.Function):
         _GradJoin.clear()                # offers of an earlier backward pass that nobody took
         ctx.save_for_backward(x, wf)
         ctx.wshape = tuple(weight.shape)
+        ctx.param_refs = (weight, bias)
         return out
 
     @staticmethod
@@ -535,8 +599,11 @@ class _Conv1x1(torch.autograd.Function):
         cout = wf.shape[0]
         gout = as_nhwc(gout.float())
         gin = empty_nhwc(n, cin, h, w, x.dtype, x.device) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(wf)
-        gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+        pw, pb = ctx.param_refs
+        gw, gb = grad_slot(pw), grad_slot(pb)       # written in place when the flat gradient buffer has an open slot
+        gw = gw.view(cout, cin) if gw is not None else torch.empty_like(wf)
+        if gb is None:
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device)
         ws = _ws(query("miseg_conv1x1_bwd_ws_bytes", n, h, w, cin, cout), x.device)
         call("miseg_conv1x1_bwd", _stream(), _DT[x.dtype], _ptr(x), _ptr(gout), n, h, w, cin, _ptr(wf), cout, _ptr(gin), _ptr(gw), _ptr(gb),
              _ptr(ws), ws.numel())
@@ -550,11 +617,12 @@ def conv1x1(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return _Conv1x1.apply(x, weight, bias)
 
 
-def count_nonfinite(grad: Tensor) -> Tensor:
+def count_nonfinite(grad: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """Device float[1]: how many entries of the fp32 tensor ``grad`` are inf or NaN (``miseg_count_nonfinite``)."""
     _need_gpu(grad)
     assert grad.dtype == torch.float32 and grad.is_contiguous()
-    out = torch.empty(1, dtype=torch.float32, device=grad.device)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=grad.device)
     call("miseg_count_nonfinite", _stream(), _ptr(grad), grad.numel(), _ptr(out))
     return out
 
@@ -568,5 +636,6 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     if guard is not None:
         _need_gpu(guard)
         assert guard.dtype == torch.float32 and guard.is_contiguous()
+    # grad_scale == 0: the kernel reads 1 / loss scale from hyper[4] (the step block: a dynamic scale under a replayed launch tape)
     call("miseg_adam_step_guarded", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1),
          float(beta2), _ptr(hyper), float(grad_scale), _ptr(guard), 0 if guard is None else guard.numel())

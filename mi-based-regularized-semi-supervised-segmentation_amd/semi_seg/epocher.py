@@ -38,8 +38,9 @@ from deepclustering2.meters2 import (AverageValueMeter, EpochResultDict, MeterIn
 from deepclustering2.optim import get_lrs_from_optimizer
 from deepclustering2.type import T_loader, T_loss, T_optim
 from deepclustering2.utils import class2one_hot
-from miseg_amd import checks, lazy, ops, unet_ops
+from miseg_amd import checks, lazy, ops, stepio, unet_ops
 from miseg_amd.lazy import LinearLoss
+from miseg_amd.tape import keep as _keep
 from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
 
 _DEBUG_ASSERTS = os.environ.get("MISEG_ASSERTS", "0") == "1"
@@ -150,6 +151,17 @@ class _Pending:
     def wait(ticket):
         """(host values, host extras) of a ``post()`` ticket; raises the deferred assertions that rode along (same errors as
         ``fetch``).  The host tensors are ring buffers: consume them before the ticket after next is posted."""
+        if isinstance(ticket, stepio.Ticket):     # the iteration's one read-back block (values | flags | [overflow count], Dice counts)
+            fields = ticket.io.wait(ticket)
+            vals = fields["scalars"].tolist()
+            out = dict(zip(ticket.names, vals))
+            checks.raise_failed(ticket.items, vals[len(ticket.names):len(ticket.names) + len(ticket.items)])
+            extras = [fields["inter"], fields["union"]]
+            if "nonfinite" in fields:
+                extras.append(fields["nonfinite"])
+            elif ticket.nvals > len(ticket.names) + len(ticket.items):      # overflow count in the slot behind the flags
+                extras.append(fields["scalars"][ticket.nvals - 1:ticket.nvals])
+            return out, tuple(extras)
         names, items, host, extras, done = ticket
         if done is not None:
             done.synchronize()
@@ -260,7 +272,6 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         assert isinstance(feature_importance, list) and isinstance(feature_importance[0], (int, float)), feature_importance
         self._feature_position, self._feature_importance = feature_position, feature_importance
         self._reducer = None  # set by miseg_amd.ddp.attach() for data-parallel runs
-        self._step_graph = None  # set by enable_step_graph()
 
     def _configure_meters(self, meters: MeterInterface) -> MeterInterface:
         meters.register_meter("lr", AverageValueMeter())
@@ -269,7 +280,7 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         meters.register_meter("sup_dice", UniversalDice(self.num_classes, report_axises=list(range(1, self.num_classes))))
         return meters
 
-    # ---- one optimisation step; leaves device scalars in self._pending
+    # ---- one optimisation step
     def _step(self, labeled_data, unlabeled_data):
         # host prelude: unpack the batches, draw the flip decisions (same draws, same order as the per-sample flips at ref :148-149)
         seed = random.randint(0, int(1e7))
@@ -280,28 +291,117 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             decisions = self._affine_transformer.decisions(ub)
         # [flips of the UB unlabeled samples | UB zeros] (the tf branch is never re-flipped)
         flip_masks = ops.flip_masks(list(decisions) + [[False, False]] * ub)
-        graph = self._step_graph
-        if graph is not None and self._reducer is None and labeled_image.is_cuda:
-            inter, union = graph.run(labeled_image, labeled_target, unlabeled_image, flip_masks, seed)
+        self._seed = seed
+        io = self._io_for(labeled_image.device)
+        tape = self._step_tape
+        if tape is not None and self._reducer is None:
+            ticket = tape.step(io, labeled_image, labeled_target, unlabeled_image, flip_masks)
         else:
-            flips2 = self._upload_flips(flip_masks, labeled_image.device)
-            self._optimizer.advance() if hasattr(self._optimizer, "advance") else None
-            inter, union = self._device_step(labeled_image, labeled_target, unlabeled_image, flips2, seed)
-        return inter, union, label_group
+            ticket = self._run_step(io, labeled_image, labeled_target, unlabeled_image, flip_masks)
+        return ticket, None, label_group
 
-    _flip_ring = None
+    _io = None
+    _step_tape = None
+    _TAPE_DEFAULT = os.environ.get("MISEG_TAPE", "1") != "0"
 
-    def _upload_flips(self, flip_masks, device) -> Tensor:
-        """The iteration's flip masks on the device.  From PINNED memory with a non-blocking copy (four slots round-robin: the host
-        runs up to two iterations ahead of the copy engine): `torch.tensor(list, device=cuda)` copies from pageable memory, which
-        hipMemcpy does synchronously -- the host then waits for the queue to drain at the top of EVERY iteration, and the launches
-        of the next step's head are exposed (a replayed step graph, which stages its masks like this, was 0.3 ms ahead of eager)."""
-        if device.type != "cuda":
-            return torch.tensor(flip_masks, dtype=torch.int32, device=device)
-        ring = self._flip_ring
-        if ring is None or ring.host.shape[1] != len(flip_masks):
-            ring = self._flip_ring = ops.PinnedRing((len(flip_masks),), torch.int32, slots=4)
-        return ring.upload(lambda slot: slot.copy_(torch.as_tensor(flip_masks, dtype=torch.int32)), device)
+    def _io_for(self, device) -> "stepio.StepIO":
+        """The iteration's two host <-> device blocks (miseg_amd.stepio); with them, unless MISEG_TAPE=0, the launch tape that replays
+        the iteration from one C call once it has run eagerly a few times (miseg_amd.tape.StepTape).  Both hang off the OPTIMISER,
+        which outlives the per-epoch epocher objects (ref semi_seg/trainer.py:197-206 builds a new epocher every epoch): the tape
+        recorded in the first epoch serves the later ones.  GPU only, like the kernels."""
+        if torch.device(device).type != "cuda":
+            from miseg_amd._cabi import MisegError
+            raise MisegError("the train step runs on the GPU only (got CPU batches); there is no CPU fallback")
+        io = self._io
+        if io is None or io.device != torch.device(device):
+            ctx = getattr(self._optimizer, "_miseg_step_ctx", None)
+            if ctx is None or ctx["io"].device != torch.device(device):
+                ctx = {"io": stepio.StepIO(device), "tape": None}
+                try:
+                    self._optimizer._miseg_step_ctx = ctx
+                except AttributeError:
+                    pass
+            io = self._io = ctx["io"]
+            self._step_ctx = ctx
+            if ctx["tape"] is not None:
+                ctx["tape"].ep = self
+                self._step_tape = ctx["tape"]
+            elif self._TAPE_DEFAULT and self._step_tape is None:
+                self.enable_step_tape()
+        return io
+
+    def enable_step_tape(self, warmup: int = 3) -> None:
+        """Replay the iteration from the library's launch tape after ``warmup`` eager iterations (one more runs eagerly while it is
+        recorded).  Data-parallel runs (a GradReducer is attached) stay eager: their collectives are issued by torch.distributed."""
+        from miseg_amd.tape import StepTape
+        self.disable_step_tape()
+        self._step_tape = StepTape(self, warmup=warmup)
+        ctx = getattr(self, "_step_ctx", None)
+        if ctx is not None:
+            ctx["tape"] = self._step_tape
+
+    def disable_step_tape(self) -> None:
+        if self._step_tape is not None:
+            self._step_tape.release()
+        self._step_tape = None
+        ctx = getattr(self, "_step_ctx", None)
+        if ctx is not None:
+            ctx["tape"] = None
+
+    def _tape_signature(self):
+        """What, besides shapes, decides the recorded launch list: the trainer kind and its loss coefficients (they are the constant
+        gradients that seed backward)."""
+        return (type(self).__name__, float(self._reg_weight), getattr(self, "_cons_weight", None), getattr(self, "_iic_weight", None),
+                tuple(self._feature_importance), tuple(self._feature_position), type(self._sup_criterion).__name__,
+                type(getattr(self, "_reg_criterion", None)).__name__)
+
+    def _loss_scale(self) -> float:
+        """Current loss scale: 1 unless the activations are IEEE half (BASELINE configs[4]); dynamic from its initial value."""
+        scale = unet_ops.loss_scale_of(self._model)
+        if scale == 1.0:
+            return 1.0
+        if not hasattr(self._optimizer, "grad_scale"):
+            raise RuntimeError("Arch.compute_dtype=float16 needs the fused Adam (Optim.name=Adam), which undoes the loss scale")
+        if self._optimizer.loss_scaler is None:
+            from miseg_amd.flat import LossScaler
+            self._optimizer.loss_scaler = LossScaler(scale)
+        return self._optimizer.loss_scaler.scale
+
+    def _stage(self, io, flip_masks) -> int:
+        """Host half of an iteration: the optimiser's step counter / scalars, the loss scale and the flip masks into the next pinned
+        slot of the step block.  No device work (a replayed launch tape calls just this)."""
+        rows = self._optimizer.host_step() if hasattr(self._optimizer, "host_step") else []
+        scale = self._loss_scale()
+        if hasattr(self._optimizer, "grad_scale"):
+            self._optimizer.grad_scale = scale
+        return io.stage(flip_masks, rows, scale)
+
+    def _run_step(self, io, labeled_image: Tensor, labeled_target: Tensor, unlabeled_image: Tensor, flip_masks):
+        """One eager iteration on the GPU: upload, forward, losses, backward, optimiser, read-back.  Returns the read-back ticket."""
+        io.upload(self._stage(io, flip_masks))
+        stepio.CURRENT = io
+        try:
+            self._device_step(labeled_image, labeled_target, unlabeled_image, io.flips())
+            return self._post(io)
+        finally:
+            stepio.CURRENT = None
+
+    def _after_replay(self) -> None:
+        unet_ops.PACK_CACHE.invalidate()       # the replay ran Adam: eager users of the weights (evaluation) must re-pack
+
+    def _post(self, io):
+        """The iteration's report (if the guarded optimiser launch has not computed it already) and the one device -> host copy."""
+        self._pending.precompute()
+        st = self._pending.take_static()
+        names, scalars, items = st if st is not None else ([], None, [])
+        rep = getattr(io, "last_report", None)
+        if scalars is not None and (rep is None or scalars.data_ptr() != rep.data_ptr()):
+            # evaluated outside the read-back block (a value that does not live in the scalar arena): copy it in
+            rep = io.out("scalars", (scalars.numel() + 1,), torch.float32)
+            rep[:scalars.numel()].copy_(scalars)
+        nvals = 0 if rep is None else rep.numel() - (0 if getattr(self._optimizer, "last_nonfinite", None) is not None and
+                                                     self._optimizer.last_nonfinite.data_ptr() == rep[-1:].data_ptr() else 1)
+        return io.post(names, items, nvals)
 
     def _before_forward(self, ub: int) -> None:   # hooks for epochers that start work while the network is still running
         pass
@@ -309,27 +409,28 @@ class TrainEpocher(_num_class_mixin, _Epocher):
     def _after_forward(self) -> None:
         pass
 
-    def enable_step_graph(self, warmup: int = 3) -> None:
-        """Replay the device half of the iteration as one hipGraph (miseg_amd.graph.StepGraph): the ~560 launches of a
-        step then cost the host one call.  Single-GPU only; data-parallel runs (a GradReducer is attached) stay eager."""
-        from miseg_amd.graph import StepGraph
-        if unet_ops.loss_scale_of(self._model) != 1.0:
-            return          # fp16 storage mode: the loss scale is dynamic (a constant inside a captured step) -> stays eager
-        self._step_graph = StepGraph(self, warmup=warmup)
-
-    def _device_step(self, labeled_image: Tensor, labeled_target: Tensor, unlabeled_image: Tensor, flips2: Tensor, seed: int):
-        """Everything of the iteration that runs on the GPU: forward, losses, backward, optimiser kernel, Dice counts.
-        No host synchronisation and no host->device traffic in here (capturable); ``optimizer.advance()`` (host) has run."""
+    def _device_step(self, labeled_image: Tensor, labeled_target: Tensor, unlabeled_image: Tensor, flips2: Tensor, seed: int = None):
+        """Everything of the iteration that runs on the GPU between the upload and the read-back: forward, losses, backward,
+        optimiser kernel, Dice counts.  No host synchronisation, no host->device traffic, and -- for the shipped trainers -- no launch
+        outside the library (so the iteration can be replayed from the launch tape); the host half (``_stage``) has run."""
+        seed = self._seed if seed is None else seed
         lb, ub = len(labeled_image), len(unlabeled_image)
         self._flips2 = flips2
         flips = flips2[:ub]
-        unlabeled_image_tf = ops.flip(unlabeled_image, flips)
+        if labeled_image.dtype == unlabeled_image.dtype == torch.float32 and labeled_image.dim() == 4 and \
+                labeled_image.shape[1:] == unlabeled_image.shape[1:] and labeled_image.is_cuda:
+            # [labeled | unlabeled | flip(unlabeled)] in one launch (ref :148-153: per-sample flips, stack, cat)
+            batch = ops.cat_flip(labeled_image, unlabeled_image, flips)
+            unlabeled_image_tf = batch[lb + ub:]
+        else:
+            unlabeled_image_tf = ops.flip(unlabeled_image, flips)
+            batch = torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0)
         assert unlabeled_image_tf.shape == unlabeled_image.shape
 
         with checks.deferred(self._pending.checks):   # simplex / NaN assertions are raised at this iteration's fetch()
             self._before_forward(ub)
             try:
-                predict_logits = self._model(torch.cat([labeled_image, unlabeled_image, unlabeled_image_tf], dim=0))
+                predict_logits = self._model(batch)
             finally:
                 self._after_forward()
         label_logits, unlabel_logits, unlabel_tf_logits = ops.split_rows(predict_logits, [lb, ub, ub])
@@ -351,17 +452,12 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         self._optimizer.zero_grad()
         if self._reducer is not None:
             self._reducer.prepare()
-        scale = unet_ops.loss_scale_of(self._model)
-        if scale != 1.0:
-            # fp16 storage mode: seed backward with the loss scale; the fused Adam reads the gradients as grad / scale, counts their
-            # non-finite entries and skips the update if there are any; the scale follows (flat.LossScaler, one iteration late)
-            if not hasattr(self._optimizer, "grad_scale"):
-                raise RuntimeError("Arch.compute_dtype=float16 needs the fused Adam (Optim.name=Adam), which undoes the loss scale")
-            if self._optimizer.loss_scaler is None:
-                from miseg_amd.flat import LossScaler
-                self._optimizer.loss_scaler = LossScaler(scale)
-            scale = self._optimizer.loss_scaler.scale
-            self._optimizer.grad_scale = scale
+        # fp16 storage mode: backward is seeded with the loss scale; the fused Adam reads the gradients as grad / scale, counts their
+        # non-finite entries and skips the update if there are any; the scale follows (flat.LossScaler, one iteration late)
+        scale = self._loss_scale()
+        if isinstance(total_loss, LinearLoss):
+            total_loss.backward(scale)
+        elif scale != 1.0:
             (total_loss * scale).backward()
         else:
             total_loss.backward()
@@ -370,15 +466,16 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         with torch.no_grad():
             self._pending.put("sup_loss", sup_loss)
             self._pending.put("reg_loss", reg_loss)
+        io = stepio.CURRENT
         if hasattr(self._optimizer, "apply"):
             # The iteration's report (meter values + the simplex / NaN flags) is computed here, in one launch, and its flags guard
             # the update on the device: the host raises a failed check one iteration late, but it has not moved the weights
             # (the reference raises before backward).
-            self._optimizer.apply(guard=self._pending.precompute() if _GUARD_STEP else None)
+            self._optimizer.apply(guard=self._pending.precompute() if _GUARD_STEP else None, io=io)
         else:
             self._optimizer.step()
         with torch.no_grad():
-            _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False)
+            _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False, to_host=True)
         self._overflow = getattr(self._optimizer, "last_nonfinite", None)     # device float[1] in the fp16 mode, else None
         return inter, union
 
@@ -406,9 +503,13 @@ class TrainEpocher(_num_class_mixin, _Epocher):
 
     _overflow = None
 
-    def _after_step(self, inter: Tensor, union: Tensor, label_group) -> None:
-        extras = (inter, union) if self._overflow is None else (inter, union, self._overflow)
-        prev, self._inflight = self._inflight, (self._pending.post(extras), label_group)
+    def _after_step(self, inter, union: Optional[Tensor], label_group) -> None:
+        if isinstance(inter, stepio.Ticket):      # the GPU path: the read-back is already under way (_post)
+            ticket = inter
+        else:
+            extras = (inter, union) if self._overflow is None else (inter, union, self._overflow)
+            ticket = self._pending.post(extras)
+        prev, self._inflight = self._inflight, (ticket, label_group)
         if not self._DEFER_FETCH:
             self._flush_records()
         elif prev is not None:
@@ -443,7 +544,7 @@ class TrainEpocher(_num_class_mixin, _Epocher):
 
     @_fused
     def regularization(self, *args, **kwargs):
-        return torch.zeros((), dtype=torch.float, device=self._device)
+        return LinearLoss([])      # symbolic zero (ref :194-197 returns a zero tensor): no kernel, reported as 0
 
 
 class UDATrainEpocher(TrainEpocher):
@@ -538,7 +639,7 @@ class IICTrainEpocher(TrainEpocher):
         projector, criterion = list(self._projectors_wrapper)[idx], list(self._IIDSegCriterionWrapper)[idx]
         main, side = torch.cuda.current_stream(feature.device), self._side(feature.device)
         ops.wait_stream(side, main)
-        feature.record_stream(side)
+        _keep(feature, side)
         with torch.cuda.stream(side):
             self._early[name] = self._tap_loss(feature, projector, criterion, self._flips2, self._ub_now)
 
@@ -551,7 +652,7 @@ class IICTrainEpocher(TrainEpocher):
             out = self._iic_body(flips, ub)
         ops.wait_stream(main, side)
         for t, _ in LinearLoss.of(out).terms:      # produced on `side`, read on `main`: keep the allocator informed
-            t.record_stream(main)
+            _keep(t, main)
         return out
 
     def _tap_loss(self, feature: Tensor, projector, criterion, flips2: Tensor, ub: int):

@@ -342,41 +342,114 @@ def test_deferred_readback_records_every_iteration_like_the_synchronous_one():
         assert torch.equal(now[keep], snap[keep]) and bool(torch.isnan(now[~keep]).all())
 
 
-def test_step_graph_replay_equals_eager_steps():
-    """The captured hipGraph of the device half of an iteration (miseg_amd.graph.StepGraph) must reproduce the eager
-    iterations: same meters and bit-identical parameters after a mix of eager warm-up, capture and replays.
-    Runs in a fresh interpreter: the capture must not follow an eager backward on the default stream in the same process
-    (miseg_amd/graph.py docstring), which the other tests of this session have already done."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import random, sys, torch
-sys.path[:0] = [%r, %r]
-import bench
-from miseg_amd import _cabi, ops
-_cabi.lib(); ops.set_mi_precision("fp32")
-def run(graph):
-    torch.manual_seed(0); random.seed(7)
-    ep, opt = bench.build_step(torch.device("cuda"), 2, 2, 64, "float32", 0)
+def _tape_run(mode_dtype, mi_precision, tape: bool, steps: int = 7, trainer: str = "udaiic"):
+    """`steps` iterations of the bench's step at a small shape; with the launch tape: 2 eager, 1 recorded, the rest replayed."""
+    import random
+    import bench
+    from miseg_amd import ops
+    ops.set_mi_precision(mi_precision)
+    torch.manual_seed(0)
+    random.seed(7)
+    ep, opt = bench.build_step(torch.device("cuda"), 2, 2, 64, mode_dtype, 0)
+    ep._TAPE_DEFAULT = False
     drv = bench.StepDriver(ep)
-    if graph:
-        ep.enable_step_graph(warmup=2)
+    if tape:
+        ep.enable_step_tape(warmup=2)
     random.seed(11)
-    for _ in range(5):   # graph: 2 eager, 1 capture + replay, 2 replays
+    for _ in range(steps):
         drv.step()
     drv.close()
-    return opt.flat.flat_param.detach().clone(), dict(ep.meters.tracking_status()), opt._steps[0]
-p_graph, m_graph, n_graph = run(True)      # first: nothing has run a backward on the default stream yet
-p_eager, m_eager, n_eager = run(False)
-assert n_eager == n_graph == 5, (n_eager, n_graph)
-assert torch.equal(p_eager, p_graph), float((p_eager - p_graph).abs().max())
-assert repr(m_eager) == repr(m_graph), (m_eager, m_graph)   # repr: the unused lr meter is nan in both
-print("GRAPH_EQUALS_EAGER")
-""" % (root, os.path.join(root, "mi-based-regularized-semi-supervised-segmentation_amd"))
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert "GRAPH_EQUALS_EAGER" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+    tp = ep._step_tape
+    info = None if tp is None else (tp.replays, tp.disabled, tp.n_ops, bool(tp.handle))
+    out = opt.flat.flat_param.detach().clone(), opt._m[0].detach().clone(), dict(ep.meters.tracking_status()), opt._steps[0], info
+    ep.disable_step_tape()
+    ops.set_mi_precision("fp32")
+    return out
+
+
+@pytest.mark.parametrize("dtype,mi", [("float32", "fp32"), ("bfloat16", "f16f8"), ("float16", "f16f8")])
+def test_step_tape_replay_equals_eager_steps(dtype, mi):
+    """The launch tape (miseg_amd.tape.StepTape: the library records its own entry-point calls during one eager iteration and issues
+    them again from one C call) must reproduce eager iterations bit for bit: same parameters, same Adam moments, same meters after a
+    mix of eager warm-up, the recorded iteration and replays with fresh batches and fresh flip decisions -- and the shipped trainer
+    must record clean (no ATen launch outside the library), i.e. the tape must really have been replayed."""
+    p_t, m_t, met_t, n_t, info = _tape_run(dtype, mi, True)
+    p_e, m_e, met_e, n_e, _ = _tape_run(dtype, mi, False)
+    assert info is not None and info[1] is None, f"the tape was refused: {info}"
+    assert info[3] and info[0] == 4, f"expected 2 eager + 1 recorded + 4 replayed iterations: {info}"
+    assert n_t == n_e == 7
+    assert torch.equal(p_e, p_t), float((p_e - p_t).abs().max())
+    assert torch.equal(m_e, m_t), float((m_e - m_t).abs().max())
+    assert repr(met_e) == repr(met_t), (met_e, met_t)     # repr: the unused lr meter is nan in both
+
+
+def test_tape_guard_sees_the_backward_thread():
+    """The recording's safety net: the ForeignOps dispatch mode must see ATen operators issued from autograd's worker thread (where
+    the backward halves of the step run), or a launch outside the library would be silently missing from every replay."""
+    from miseg_amd.tape import ForeignOps
+
+    class Leaky(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g + 1.0            # an ATen launch on the engine's thread
+
+    x = torch.ones(8, device="cuda", requires_grad=True)
+    guard = ForeignOps()
+    with guard:
+        y = Leaky.apply(x)
+        y.backward(torch.ones(8, device="cuda").expand(8))
+    assert any(n.startswith("aten::add") for n in guard.seen), guard.seen
+    guard = ForeignOps()
+    with guard:
+        v = torch.empty(4, 4, device="cuda").view(16)[2:6].detach()
+        torch.zeros(3)                # host tensors do not count
+    assert guard.seen == [], guard.seen
+
+
+def test_fp16_dynamic_loss_scale_under_the_tape():
+    """fp16 storage mode under the launch tape: the loss scale lives in the step block (seeds = coefficient x scale, hyper[4] = 1 /
+    scale), so an overflow during REPLAYED iterations still skips the update on the device and halves the scale on the host."""
+    import random
+    import bench
+    from miseg_amd import ops
+    from miseg_amd.flat import LossScaler
+    ops.set_mi_precision("f16f8")
+    torch.manual_seed(0)
+    random.seed(3)
+    ep, opt = bench.build_step(torch.device("cuda"), 2, 2, 64, "float16", 0)
+    ep._TAPE_DEFAULT = False
+    drv = bench.StepDriver(ep)
+    ep.enable_step_tape(warmup=2)
+    try:
+        for _ in range(4):               # 2 eager, 1 recorded, 1 replayed at the default scale
+            drv.step()
+        ep._flush_records()
+        tp = ep._step_tape
+        assert tp.disabled is None and tp.replays == 1, (tp.disabled, tp.replays)
+        scaler = opt.loss_scaler
+        assert isinstance(scaler, LossScaler) and scaler.overflows == 0
+        before = opt.flat.flat_param.detach().clone()
+        scaler.scale = 2.0 ** 40         # every half-precision activation gradient overflows
+        with pytest.warns(UserWarning, match="overflow"):
+            for _ in range(3):
+                drv.step()
+            ep._flush_records()
+        assert tp.replays == 4
+        assert torch.equal(opt.flat.flat_param.detach(), before)        # three skipped updates
+        assert scaler.scale == 2.0 ** 37 and scaler.overflows == 3
+        scaler.scale = 16384.0
+        for _ in range(2):
+            drv.step()
+        ep._flush_records()
+        assert not torch.equal(opt.flat.flat_param.detach(), before)    # updates resume at a sane scale
+    finally:
+        drv.close()
+        ep.disable_step_tape()
+        ops.set_mi_precision("fp32")
 
 
 def test_bench_line_contract():
