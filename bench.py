@@ -363,12 +363,12 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"built step: world={world} LB=UB={args.lb} {args.size}x{args.size} {args.dtype}")
-    # The launch tape (default on one GPU; data-parallel runs stay eager): iterations 0-2 run eagerly, iteration 3 eagerly while the
+    # The launch tape (default): iterations 0-2 run eagerly, iteration 3 eagerly while the
     # library records its calls, everything after is replayed.  Per-kernel HIP-event timing of EVERY entry point costs host time (two
     # events per call), so the full table is taken over eager warm-up iterations; inside the timed region only the dominant kernel is
     # timed, live, on the stream it is launched on: by the tape itself when it replays (miseg_tape_time_op), by the ctypes wrapper
     # when the run is eager.
-    use_tape = world == 1 and not distributed and not args.eager
+    use_tape = not args.eager      # data-parallel runs too: their all-reduces are host calls between segments of the tape
     if not use_tape:
         ep._TAPE_DEFAULT = False
     eager_warm = min(3, args.warmup) if use_tape else args.warmup

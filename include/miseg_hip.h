@@ -467,7 +467,7 @@ int miseg_adam_step_scaled(void* stream, float* param, const float* grad, float*
 /* ... and guarded: guard = nguard fp32 flags in device memory (the iteration's deferred assertion / NaN flags); if any of them is
  * non-zero or NaN the launch changes nothing -- parameters and moments stay as the reference, which raises before backward
  * (iic_loss.py:147-148, semi_seg/epocher.py:129-130), would have left them.  nguard == 0: miseg_adam_step_scaled.
- * grad_scale == 0: the loss scale lives on the device, hyper is fp32[5] and hyper[4] = 1 / scale (a dynamic loss scale under a
+ * grad_scale == -1: the loss scale lives on the device, hyper is fp32[5] and hyper[4] = 1 / scale (a dynamic loss scale under a
  * replayed launch tape, whose by-value arguments are fixed). */
 int miseg_adam_step_guarded(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t numel, float beta1, float beta2, const float* hyper, float grad_scale,

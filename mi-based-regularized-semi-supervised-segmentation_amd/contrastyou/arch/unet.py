@@ -87,10 +87,14 @@ class UNet(nn.Module):
     dimension_dict = {"Conv1": 16, "Conv2": 32, "Conv3": 64, "Conv4": 128, "Conv5": 256,
                       "Up_conv5": 128, "Up_conv4": 64, "Up_conv3": 32, "Up_conv2": 16}
 
-    def __init__(self, input_dim: int = 3, num_classes: int = 1, compute_dtype="float32"):
+    def __init__(self, input_dim: int = 3, num_classes: int = 1, compute_dtype="float32", mi_precision: Optional[str] = None):
+        """``compute_dtype`` / ``mi_precision`` are this repo's two additions to ``config/semi.yaml``'s ``Arch`` section (ref
+        config/semi.yaml:3-5 has input_dim and num_classes): the storage / MFMA operand type of the network, and the arithmetic of the
+        local-MI contraction that the trainers apply through ``miseg_amd.ops.resolve_mi_precision`` (default by compute_dtype)."""
         super().__init__()
         self.input_dim, self.num_classes = input_dim, num_classes
         self.compute_dtype = dt = _as_dtype(compute_dtype)
+        self.mi_precision = None if mi_precision in (None, "", "auto") else str(mi_precision)
         widths = [16, 32, 64, 128, 256]
         for i in range(1, 5):
             setattr(self, f"Maxpool{i}", _FusedMaxPool(kernel_size=2, stride=2))

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     for (int i = 0; i < nguard; ++i)
         if (!(guard[i] == 0.f)) return;
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2], wd = hyper[3];
-    if (inv_scale <= 0.f) inv_scale = hyper[4];      // the loss scale lives on the device (dynamic scale under a replayed launch tape)
+    if (inv_scale < 0.f) inv_scale = hyper[4];       // the loss scale lives on the device (dynamic scale under a replayed launch tape)
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * inv_scale + wd * p[i];
         float mi = m[i] * b1 + (1.f - b1) * gi;
@@ -652,10 +652,10 @@ extern "C" int miseg_adam_step_guarded(void* stream, float* param, const float* 
                                        float beta1, float beta2, const float* hyper, float grad_scale, const float* guard, int64_t nguard) {
     MISEG_TAPE(miseg_adam_step_guarded, stream, param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2, hyper, grad_scale, guard, nguard);
     MISEG_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper && numel > 0, "adam_step: bad args");
-    MISEG_REQUIRE(grad_scale >= 0.f && std::isfinite(grad_scale), "adam_step: grad_scale must be a positive finite number (or 0: read 1 / scale from hyper[4])");
+    MISEG_REQUIRE((grad_scale > 0.f || grad_scale == -1.f) && std::isfinite(grad_scale), "adam_step: grad_scale must be a positive finite number (or -1: read 1 / scale from hyper[4])");
     MISEG_REQUIRE(nguard >= 0 && nguard <= 1024 && (nguard == 0 || guard), "adam_step: bad guard");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(numel)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, numel, beta1, beta2,
-                       hyper, grad_scale > 0.f ? 1.f / grad_scale : 0.f, guard, (int)nguard);
+                       hyper, grad_scale > 0.f ? 1.f / grad_scale : -1.f, guard, (int)nguard);
     MISEG_LAUNCH_CHECK("adam_kernel");
     return MISEG_OK;
 }

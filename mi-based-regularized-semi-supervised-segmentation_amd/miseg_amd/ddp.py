@@ -131,25 +131,49 @@ class GradReducer:
         torch.cuda.set_stream(rs)       # (not the `with torch.cuda.stream` context: 15-20 us of host time per use)
         try:
             self.flat.collect(lo, hi)   # joins the weight-gradient stream into rs; gradients autograd parked elsewhere -> flat slice
-            self._handles[b] = dist.all_reduce(self.flat.flat_grad[start:end], op=op, group=self.group, async_op=True)
         finally:
             torch.cuda.set_stream(cur)
+
+        def allreduce():                # host call: under a launch tape it is repeated between two segments of every replay, from
+            back = torch.cuda.current_stream(dev)      # the caller's thread -- so it sets (and restores) its own stream
+            torch.cuda.set_stream(rs)
+            try:
+                self._handles[b] = dist.all_reduce(self.flat.flat_grad[start:end], op=op, group=self.group, async_op=True)
+            finally:
+                torch.cuda.set_stream(back)
+        from .tape import host_call
+        host_call(allreduce)
 
     def prepare(self) -> None:
         """Call after zero_grad(), before backward()."""
         self.flat.ensure()
         self._pending = [hi - lo for lo, hi, _, _ in self.buckets]
         self._handles = [None] * len(self.buckets)
+        if self._triggers_only and any(p.grad is not None for p in self.flat.params):
+            # trigger-only mode decides "bucket complete" from `grad is not None`: a gradient left over from an earlier pass (gradient
+            # accumulation, a zero_grad that keeps the tensors) would let a trigger reduce a half-written bucket -> count arrivals again
+            for h in self._hook_handles:
+                h.remove()
+            self._hook_handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.flat.params)]
+            self._triggers_only = False
+            self._stale_grads = True
         self._armed = True
 
     def finish(self) -> None:
         """Call after backward(), before optimizer.step(): flush unlaunched buckets, wait, average."""
         self._armed = False
-        if not self._triggers_only:
+        if not self._triggers_only and not getattr(self, "_stale_grads", False):
             self._keep_trigger_hooks()
         for b in range(len(self.buckets)):
             if self._handles[b] is None:  # some parameter of the bucket got no gradient this step (or its trigger fired early)
                 self._launch(b)
+        if self.flat.flat_grad.is_cuda:
+            from .tape import host_call
+            host_call(self._wait_all)     # (a replayed launch tape repeats it at this point of the iteration)
+        else:
+            self._wait_all()
+
+    def _wait_all(self) -> None:
         timed = self.timing and self.flat.flat_grad.is_cuda
         if timed:       # from "this stream has nothing left but to wait for the collectives" to "they are done": the EXPOSED part
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -269,7 +269,7 @@ class FusedAdam(torch.optim.Optimizer):
                     unet_ops.count_nonfinite(fb.flat_grad, out=bad)
                     self.last_nonfinite = bad
                     guard = io.guard_with_overflow(guard, bad)
-                    scale = 0.0                            # 1 / loss scale is hyper[4] of the step block
+                    scale = -1.0                           # 1 / loss scale is hyper[4] of the step block
                 unet_ops.adam_step(fb.flat_param, fb.flat_grad, self._m[gi], self._v[gi], io.hyper(gi), b1, b2, scale, guard)
             unet_ops.PACK_CACHE.invalidate()
             return

@@ -175,6 +175,21 @@ def set_mi_precision(mode: str) -> None:
     _mi_precision = MI_PRECISIONS[mode]
 
 
+def resolve_mi_precision(compute_dtype, requested: Optional[str] = None) -> str:
+    """The local-MI arithmetic a trainer runs with: the ``MISEG_MI_PRECISION`` environment variable if set (an override for A/B
+    runs), else the model's ``Arch.mi_precision`` config key, else by the U-Net's storage type -- exact fp32 MFMA for
+    ``Arch.compute_dtype=float32`` (the parity mode), the f16 + fp8 split for bfloat16 / float16 (the benchmarked arithmetic)."""
+    env = os.environ.get("MISEG_MI_PRECISION")
+    mode = env or requested or ("fp32" if compute_dtype in (torch.float32, "float32", "fp32", None) else "f16f8")
+    if mode not in MI_PRECISIONS:
+        raise ValueError(f"mi_precision must be one of {sorted(MI_PRECISIONS)}, got {mode!r}")
+    return mode
+
+
+def mi_precision_name() -> str:
+    return next(k for k, v in MI_PRECISIONS.items() if v == _mi_precision)
+
+
 def colour_windows(windows: Sequence[Tuple[int, int, int, int]]) -> List[List[int]]:
     """Greedy colouring of overlapping windows into pairwise-disjoint groups (deterministic backward:
     each group is one launch with plain read-modify-write, groups run in stream order)."""

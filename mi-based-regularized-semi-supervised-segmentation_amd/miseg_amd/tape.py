@@ -63,6 +63,8 @@ class ForeignOps(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         out = func(*args, **kwargs)
+        if _IN_HOST_CALL:
+            return out
         name = func._schema.name + ("." + func._schema.overload_name if func._schema.overload_name else "")
         if name not in _HARMLESS and (_has_cuda(args) or _has_cuda(list(kwargs.values())) or _has_cuda(out)):
             import traceback
@@ -79,6 +81,25 @@ class ForeignOps(TorchDispatchMode):
 
 
 KEEP_ALIVE: Optional[list] = None      # while recording: tensors handed to another stream (see keep)
+HOST_CALLS: Optional[list] = None      # while recording: the host-side calls between tape segments (see host_call)
+_IN_HOST_CALL = 0
+
+
+def host_call(fn):
+    """Run ``fn()`` -- host-side work in the MIDDLE of an iteration that issues device work the library does not see (an RCCL
+    all-reduce through torch.distributed, the wait for it).  While an iteration is being recorded the call also cuts the tape: the
+    launches so far form one segment, ``fn`` is remembered, and a replay runs segment, ``fn()``, next segment ... in the recorded
+    order.  ``fn`` must not depend on the thread that calls it (it sets its own stream): at replay that is the caller's thread, at
+    record time it may be autograd's.  What ``fn`` launches is its own business -- the recording's ATen watch ignores it."""
+    global _IN_HOST_CALL
+    if _cabi.RECORDING and HOST_CALLS is not None:
+        _cabi.lib().miseg_tape_mark(_cabi.RECORDING)
+        HOST_CALLS.append(fn)
+    _IN_HOST_CALL += 1
+    try:
+        return fn()
+    finally:
+        _IN_HOST_CALL -= 1
 
 
 def keep(t: Optional[Tensor], stream) -> None:
@@ -110,6 +131,7 @@ class StepTape:
         self.n_ops = 0
         self.replays = 0
         self.tags: list = []        # (op index, tag, (flops, bytes)) of the recorded iteration's tagged calls
+        self.host_calls: list = []  # host-side calls between the tape's segments, in order (host_call)
         self._values = None
 
     def __del__(self):
@@ -129,7 +151,7 @@ class StepTape:
         from . import ops, unet_ops
         return (tuple(li.shape), tuple(lt.shape), tuple(ui.shape), li.dtype, lt.dtype, ui.dtype, li.is_contiguous(), lt.is_contiguous(),
                 ui.is_contiguous(), n_masks, ops._stream(), ops._mi_precision, id(io), unet_ops.PACK_CACHE.generation,
-                self.ep._model.training, self.ep._tape_signature())
+                self.ep._model.training, self.ep._tape_signature(), id(getattr(self.ep, "_reducer", None)))
 
     def step(self, io, li: Tensor, lt: Tensor, ui: Tensor, flip_masks):
         ep = self.ep
@@ -147,17 +169,17 @@ class StepTape:
 
     # ------------------------------------------------------------------ record
     def _record(self, io, li, lt, ui, flip_masks, key):
-        global KEEP_ALIVE
+        global KEEP_ALIVE, HOST_CALLS
         ep = self.ep
         lib = _cabi.lib()
         dev = li.device
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         pool = torch.cuda.MemPool()
         guard = ForeignOps()
-        KEEP_ALIVE = []
+        KEEP_ALIVE, HOST_CALLS = [], []
         handle = lib.miseg_tape_begin()
         if not handle:
-            KEEP_ALIVE = None
+            KEEP_ALIVE = HOST_CALLS = None
             return ep._run_step(io, li, lt, ui, flip_masks)
         torch._C._cuda_beginAllocateToPool(idx, pool.id)       # every thread's allocations (the backward pass runs on the engine's)
         _cabi.RECORDING, _cabi.TAPE_TAGS = handle, []
@@ -170,6 +192,7 @@ class StepTape:
             torch._C._cuda_releasePool(idx, pool.id)
             lib.miseg_tape_end(handle)
             _cabi.RECORDING = 0
+            host_calls, HOST_CALLS = HOST_CALLS, None
             KEEP_ALIVE = None
         self.tags = list(_cabi.TAPE_TAGS)
         self.attempts += 1
@@ -203,7 +226,12 @@ class StepTape:
             self.disabled = f"unexpected staging traffic in the recorded iteration ({uses})"
             warnings.warn(f"launch tape not used, the iteration stays eager ({self.disabled})")
             return ticket
-        self.handle, self.key, self.pool = handle, key, pool
+        if lib.miseg_tape_segments(handle) != len(host_calls) + 1:
+            lib.miseg_tape_free(handle)
+            self.disabled = "segment marks and host calls of the recorded iteration do not pair up"
+            warnings.warn(f"launch tape not used, the iteration stays eager ({self.disabled})")
+            return ticket
+        self.handle, self.key, self.pool, self.host_calls = handle, key, pool, host_calls
         self.static = (ticket.fields, ticket.names, ticket.items, ticket.nvals)
         self.n_ops = lib.miseg_tape_len(handle)
         self.uses = uses
@@ -221,10 +249,13 @@ class StepTape:
         v[0], v[1], v[2] = li.data_ptr(), lt.data_ptr(), ui.data_ptr()
         v[3], v[4] = io.host[slot].data_ptr(), io.up_events[slot]
         v[5], v[6] = io.out_host[oslot].data_ptr(), io.out_events[oslot]
-        rc = lib.miseg_tape_replay(self.handle, 0, v, len(v))
-        if rc != 0:
-            msg = lib.miseg_last_error()
-            raise _cabi.MisegError(f"miseg_tape_replay failed ({rc}): {msg.decode() if msg else ''}")
+        for seg in range(len(self.host_calls) + 1):
+            rc = lib.miseg_tape_replay(self.handle, seg, v, len(v))
+            if rc != 0:
+                msg = lib.miseg_last_error()
+                raise _cabi.MisegError(f"miseg_tape_replay failed ({rc}): {msg.decode() if msg else ''}")
+            if seg < len(self.host_calls):
+                self.host_calls[seg]()         # e.g. the all-reduce of a gradient bucket (miseg_amd.ddp.GradReducer)
         io.up_pending[slot] = True
         self.replays += 1
         ep._after_replay()

@@ -42,10 +42,14 @@ def wgrad_stream(device):
 
 
 def join_wgrad_streams() -> None:
-    """Make the current stream wait for every outstanding side-stream wgrad."""
+    """Make the current stream wait for every outstanding side-stream wgrad.  Called with the weight-gradient stream itself current (the
+    data-parallel reducer launches its collectives from it) there is nothing to wait for and the device stays marked: the backward
+    pass's own stream still has to join when the pass ends."""
     for dev in list(_wgrad_dirty):
-        wait_stream(torch.cuda.current_stream(dev), _wgrad_streams[dev])
-    _wgrad_dirty.clear()
+        cur = torch.cuda.current_stream(dev)
+        if cur != _wgrad_streams[dev]:
+            wait_stream(cur, _wgrad_streams[dev])
+            _wgrad_dirty.discard(dev)
 
 
 _FUSE_UPS_DGRAD = True   # False: conv3x3 dgrad + miseg_sumpool2x2 as two launches
@@ -636,6 +640,6 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     if guard is not None:
         _need_gpu(guard)
         assert guard.dtype == torch.float32 and guard.is_contiguous()
-    # grad_scale == 0: the kernel reads 1 / loss scale from hyper[4] (the step block: a dynamic scale under a replayed launch tape)
+    # grad_scale == -1: the kernel reads 1 / loss scale from hyper[4] (the step block: a dynamic scale under a replayed launch tape)
     call("miseg_adam_step_guarded", _stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(beta1),
          float(beta2), _ptr(hyper), float(grad_scale), _ptr(guard), 0 if guard is None else guard.numel())

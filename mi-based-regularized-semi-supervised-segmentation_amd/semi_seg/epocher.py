@@ -294,7 +294,7 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         self._seed = seed
         io = self._io_for(labeled_image.device)
         tape = self._step_tape
-        if tape is not None and self._reducer is None:
+        if tape is not None and (self._reducer is None or self._reducer.flat.flat_grad.is_cuda):
             ticket = tape.step(io, labeled_image, labeled_target, unlabeled_image, flip_masks)
         else:
             ticket = self._run_step(io, labeled_image, labeled_target, unlabeled_image, flip_masks)
@@ -332,7 +332,8 @@ class TrainEpocher(_num_class_mixin, _Epocher):
 
     def enable_step_tape(self, warmup: int = 3) -> None:
         """Replay the iteration from the library's launch tape after ``warmup`` eager iterations (one more runs eagerly while it is
-        recorded).  Data-parallel runs (a GradReducer is attached) stay eager: their collectives are issued by torch.distributed."""
+        recorded).  In data-parallel runs the bucket all-reduces and the wait for them stay host calls between segments of the tape
+        (miseg_amd.tape.host_call)."""
         from miseg_amd.tape import StepTape
         self.disable_step_tape()
         self._step_tape = StepTape(self, warmup=warmup)

@@ -75,6 +75,10 @@ class SemiTrainer(Trainer):
 
     def _init(self) -> None:
         section = self._config["Trainer"]
+        # arithmetic of the local-MI contraction: Arch.mi_precision, else by Arch.compute_dtype (f16f8 for bfloat16 / float16)
+        from miseg_amd import ops
+        net = getattr(self._model, "module", self._model)
+        ops.set_mi_precision(ops.resolve_mi_precision(getattr(net, "compute_dtype", None), getattr(net, "mi_precision", None)))
         self.set_feature_positions(section["feature_names"])
         raw = section["feature_importance"]
         assert isinstance(raw, list), type(raw)

@@ -67,6 +67,44 @@ def test_main_cli_non_default_iic_configuration():
         shutil.rmtree(run_dir, ignore_errors=True)
 
 
+@pytest.mark.parametrize("extra,expect", [([], "f16f8"), (["Arch.mi_precision=bf16x3"], "bf16x3"), (["Arch.compute_dtype=float32"], "fp32")])
+def test_main_entry_point_selects_the_benchmarked_arithmetic(monkeypatch, extra, expect):
+    """`python semi_seg/main.py Trainer.name=udaiic Arch.compute_dtype=bfloat16` -- the reference's surface (ref semi_seg/main.py:19-44,
+    config/semi.yaml:3-5) -- must run the arithmetic bench.py measures: the f16 + fp8 local-MI split by default for 16-bit storage
+    (`Arch.mi_precision` overrides, float32 storage stays exact fp32), no environment variable involved.  The local-MI backward
+    launches of the run are watched at the C boundary (the pad-3 tap of K = 20 x 5 sub-heads with precision 3 IS the fp8 kernel,
+    csrc/mi_local.hip dispatch), and the later iterations come from the launch tape."""
+    sys.path.insert(0, PKG)
+    monkeypatch.delenv("MISEG_MI_PRECISION", raising=False)
+    import semi_seg.main as M
+    from miseg_amd import ops
+    seen = []
+    real = ops.call
+
+    def spy(name, *a, **k):
+        if name == "miseg_iic_local_bwd_heads":
+            seen.append((int(a[7]), int(a[14])))          # (pad, precision)
+        return real(name, *a, **k)
+    monkeypatch.setattr(ops, "call", spy)
+    save = f"pytest_cli_prec_{expect}"
+    run_dir = os.path.join(PKG, "semi_seg", "runs", save)
+    shutil.rmtree(run_dir, ignore_errors=True)
+    try:
+        argv = ["Trainer.name=udaiic", f"Trainer.save_dir={save}", "Trainer.device=cuda", "Trainer.max_epoch=2", "Trainer.num_batches=6",
+                "Data.name=synthetic", "Data.size=64", "LabeledData.batch_size=2", "UnlabeledData.batch_size=2"] + \
+            ([] if any(e.startswith("Arch.compute_dtype") for e in extra) else ["Arch.compute_dtype=bfloat16"]) + extra
+        trainer = M.main(argv)
+        assert ops.mi_precision_name() == expect
+        assert seen and all(p == ops.MI_PRECISIONS[expect] for _, p in seen), seen
+        assert any(pad == 3 for pad, _ in seen)
+        tape = trainer._optimizer._miseg_step_ctx["tape"]
+        assert tape is not None and tape.disabled is None and tape.replays >= 6, (tape and tape.disabled, tape and tape.replays)
+        assert len(seen) == 2 * 4, seen                   # two decoder taps x (3 eager + 1 recorded) iterations: the rest were replayed
+    finally:
+        shutil.rmtree(run_dir, ignore_errors=True)
+        ops.set_mi_precision("fp32")
+
+
 def test_trainer_inference_dumps_pngs_and_reports_hausdorff(tmp_path):
     """SemiTrainer.inference (ref semi_seg/trainer.py:109-124 -> InferenceEpocher, epocher.py:76-107)."""
     sys.path.insert(0, PKG)

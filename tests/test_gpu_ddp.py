@@ -51,6 +51,30 @@ def test_two_rank_step_reduces_to_the_mean_of_the_shard_gradients(tmp_path, dtyp
     assert float((singles[0]["grad"] - singles[1]["grad"]).abs().max()) > 1e-3 * scale     # the shards really differ
 
 
+def test_two_rank_launch_tape_equals_two_rank_eager(tmp_path):
+    """The data-parallel iteration under the launch tape: the bucket all-reduces and the wait for them are host calls between the
+    tape's segments (miseg_amd.tape.host_call), repeated at every replay.  Seven iterations of two ranks (gloo, both on the one GPU):
+    three eager, one recorded, three replayed -- parameters must equal, bit for bit, those of the same job run eagerly throughout."""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    results = {}
+    for mode, tape in (("tape", "1"), ("eager", "0")):
+        port = 36500 + (os.getpid() + (7 if tape == "1" else 0)) % 2000
+        procs = []
+        for r in range(2):
+            env = dict(base, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MISEG_DDP_BACKEND="gloo",
+                       MISEG_TAPE=tape, MISEG_TAPE_QUIET="0")
+            procs.append(_run([r, tmp_path / f"{mode}{r}.pt", "bfloat16", 7], env=env))
+        outs = [p.communicate(timeout=900)[0] for p in procs]
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o[-3000:]
+        results[mode] = [torch.load(tmp_path / f"{mode}{r}.pt") for r in range(2)]
+    t0, t1 = results["tape"]
+    assert t0["tape_refused"] is None and t0["tape_replays"] == 3 and t0["tape_host_calls"] == 4, (t0["tape_refused"], t0["tape_replays"], t0["tape_host_calls"])
+    assert torch.equal(t0["param_after"], t1["param_after"])
+    assert results["eager"][0]["tape_replays"] == 0
+    assert torch.equal(t0["param_after"], results["eager"][0]["param_after"])
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: the test box has a single GPU (the driver's 8-GPU node runs it)")
 def test_two_rank_step_over_rccl(tmp_path):
     """The same two-rank step over the `nccl` backend (= RCCL on ROCm), one GPU per rank: bucketed asynchronous all-reduce (native AVG)

@@ -259,7 +259,8 @@ def _oracle_names(g, mode):
     return to_ref
 
 
-def test_step_gradients_bf16_match_bf16_emulation_and_track_reference(golden, monkeypatch):
+@pytest.mark.parametrize("mi_precision", ["f16f8", "bf16x3"])
+def test_step_gradients_bf16_match_bf16_emulation_and_track_reference(golden, monkeypatch, mi_precision):
     """The bench's arithmetic (bf16 activations and activation gradients, bf16x3 local MI), iteration-1 gradients of every
     parameter against
       (a) the CPU oracle step with the SAME rounding points (oracle.unet.unet_forward_bf16_autograd: straight-through bf16
@@ -270,13 +271,13 @@ def test_step_gradients_bf16_match_bf16_emulation_and_track_reference(golden, mo
     from miseg_amd import ops as _ops
     from oracle import step as OS
     g = golden("step")
-    _ops.set_mi_precision("bf16x3")
+    _ops.set_mi_precision(mi_precision)       # f16f8 = what `Arch.compute_dtype=bfloat16` and bench.py run by default
     try:
         grads = _first_iteration_gradients("udaiic", "bfloat16", monkeypatch)
     finally:
         _ops.set_mi_precision("fp32")
     rows = _gradient_errors(g, "udaiic", grads)
-    _dump("udaiic_bf16_vs_fp32_reference", rows)
+    _dump(f"udaiic_bf16_{mi_precision}_vs_fp32_reference", rows)
     sig = {k: v[0] for k, v in rows.items() if v[2] > 1e-7}
     assert max(sig.values()) < 1.3, {k: v for k, v in sig.items() if v >= 1.3}
     assert sig["DeConv_1x1.weight"] < 3e-2 and sig["Up_conv2.conv.3.weight"] < 0.3
@@ -296,7 +297,7 @@ def test_step_gradients_bf16_match_bf16_emulation_and_track_reference(golden, mo
         mine, ref = grads[to_ref(n)].astype(np.float64), ge.numpy().astype(np.float64)
         emu_rows[to_ref(n)] = (float(np.linalg.norm(mine - ref) / (np.linalg.norm(ref) + 1e-30)),
                                float(np.abs(mine - ref).max() / (np.abs(ref).max() + 1e-30)), float(np.abs(ref).max()))
-    _dump("udaiic_bf16_vs_bf16_emulation", emu_rows)
+    _dump(f"udaiic_bf16_{mi_precision}_vs_bf16_emulation", emu_rows)
     sig = {k: v[0] for k, v in emu_rows.items() if v[2] > 1e-7}
     # Measured (round 2): logits layer 2.6e-3, decoder-tap heads 3.5e-3 / 1.9e-2, Up_conv2.conv.3 7e-2, then growing steadily to
     # 0.48 at Conv1 -- two bf16 evaluations with different accumulation order decorrelate with depth on a RANDOM-INIT ReLU+BatchNorm
@@ -636,8 +637,27 @@ def _cfg2_oracle():
                                       iic_weight=0.1, do_update=False)
         finally:
             torch.set_num_threads(threads)
-        _CFG2_ORACLE.update(heads=heads, limg=limg, ltgt=ltgt, uimg=uimg, sc=sc, grads=grads)
+        _CFG2_ORACLE.update(heads=heads, limg=limg, ltgt=ltgt, uimg=uimg, sc=sc, grads=grads, seed=seed)
     return _CFG2_ORACLE
+
+
+def _cfg2_oracle_bf16():
+    """The same step with the U-Net's bf16 rounding points emulated on the CPU (oracle.unet.unet_forward_bf16_autograd: every stored
+    activation and activation gradient rounded to bf16, straight through): what the bf16 HIP step is held against -- the fp32 oracle
+    differs from any bf16 evaluation of this random-init net by 10-25 % in the consistency term alone."""
+    o = _cfg2_oracle()
+    if "sc_bf16" not in o:
+        from oracle import step as OS
+        state = OS.StepState(OU.init_state(1, 4, seed=40), o["heads"], lr=1e-3, weight_decay=1e-5)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
+        try:
+            sc, grads = OS.train_step(state, o["limg"], o["ltgt"], o["uimg"], o["seed"], mode="udaiic", feature_importance=[0.5, 0.25, 0.25],
+                                      cons_weight=5.0, iic_weight=0.1, do_update=False, unet_fn=OU.unet_forward_bf16_autograd)
+        finally:
+            torch.set_num_threads(threads)
+        o.update(sc_bf16=sc, grads_bf16=grads)
+    return o
 
 
 @pytest.mark.parametrize("dtype,mi_precision", [("float32", "fp32"), ("bfloat16", "f16f8"), ("bfloat16", "bf16x3")])
@@ -687,17 +707,22 @@ def test_whole_step_at_the_bench_shape_matches_the_oracle(monkeypatch, dtype, mi
                             feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1).run()
     finally:
         _ops.set_mi_precision("fp32")
-    sc = o["sc"]
     exact = dtype == "float32"
-    np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5 if exact else 2e-2)
-    np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4 if exact else 0.25)
+    sc = o["sc"] if exact else _cfg2_oracle_bf16()["sc_bf16"]       # bf16 storage: against the oracle with the same rounding points
+    _dump(f"cfg2shape_scalars_{dtype}_{mi_precision}", {k: (abs(res[k]["mean"] - sc[k]) / (abs(sc[k]) + 1e-30), res[k]["mean"], sc[k])
+                                                         for k in ("sup_loss", "uda", "mi", "reg_loss")})
+    np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5 if exact else 5e-3)
+    np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4 if exact else 2e-2)
     if exact:
         np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
         for f in FEATURES:
             np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
         np.testing.assert_allclose(res["reg_loss"]["mean"], sc["reg_loss"], rtol=2e-4, atol=1e-7)
     else:
-        assert abs(res["mi"]["mean"] - sc["mi"]) < 0.5 * abs(sc["mi"]) + 1e-4
+        np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=5e-2, atol=2e-6)
+        for f in FEATURES:
+            np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=5e-2, atol=2e-6)
+        np.testing.assert_allclose(res["reg_loss"]["mean"], sc["reg_loss"], rtol=2e-2, atol=1e-6)
     flat, fb = grabbed[0].cpu() / float(opt.grad_scale), opt.flat
     pref = {"Conv5": pw._encoder_projectors["Conv5"], "Up_conv3": pw._decoder_projectors["Up_conv3"], "Up_conv2": pw._decoder_projectors["Up_conv2"]}
     worst = {}
@@ -852,17 +877,35 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
                 cons_weight=5.0, iic_weight=0.1, num_classes=NC, do_update=False)
         finally:
             torch.set_num_threads(threads)
-    sc, grads = _CFG4_ORACLE["sc"], _CFG4_ORACLE["grads"]
     exact = dtype == "float32"
-    np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5 if exact else 2e-2)
-    np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4 if exact else 0.25)
+    if not exact and "sc_bf16" not in _CFG4_ORACLE:     # bf16 storage: the oracle with the same rounding points (another CPU minute)
+        random.seed(1357)
+        seed = random.randint(0, int(1e7))
+        state = OS.StepState(OU.init_state(1, NC, seed=50), heads, lr=1e-3, weight_decay=1e-5)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
+        try:
+            _CFG4_ORACLE["sc_bf16"], _CFG4_ORACLE["grads_bf16"] = OS.train_step(
+                state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], paddings=[1, 3], patch_sizes=[PATCH, PATCH],
+                cons_weight=5.0, iic_weight=0.1, num_classes=NC, do_update=False, unet_fn=OU.unet_forward_bf16_autograd)
+        finally:
+            torch.set_num_threads(threads)
+    sc, grads = (_CFG4_ORACLE["sc"], _CFG4_ORACLE["grads"])
+    if not exact:
+        sc = _CFG4_ORACLE["sc_bf16"]
+    _dump(f"cfg4_scalars_{dtype}_{mi_precision}", {k: (abs(res[k]["mean"] - sc[k]) / (abs(sc[k]) + 1e-30), res[k]["mean"], sc[k])
+                                                    for k in ("sup_loss", "uda", "mi", "reg_loss")})
+    np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5 if exact else 5e-3)
+    np.testing.assert_allclose(res["uda"]["mean"], sc["uda"], rtol=2e-4 if exact else 2e-2)
     if exact:
         np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=2e-3, atol=2e-6)
         for f in FEATURES:
             np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=2e-3, atol=2e-6)
         np.testing.assert_allclose(res["reg_loss"]["mean"], sc["reg_loss"], rtol=2e-4, atol=1e-7)
     else:
-        assert abs(res["mi"]["mean"] - sc["mi"]) < 0.5 * abs(sc["mi"]) + 1e-4
+        np.testing.assert_allclose(res["mi"]["mean"], sc["mi"], rtol=5e-2, atol=2e-6)
+        for f in FEATURES:
+            np.testing.assert_allclose(res["individual_mis"][f], sc[f"mi/{f}"], rtol=5e-2, atol=2e-6)
     flat, fb = grabbed[0].cpu() / float(opt.grad_scale), opt.flat
     pref = {"Conv5": pw._encoder_projectors["Conv5"], "Up_conv3": pw._decoder_projectors["Up_conv3"], "Up_conv2": pw._decoder_projectors["Up_conv2"]}
     worst = {}
