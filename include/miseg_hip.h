@@ -97,6 +97,11 @@ int miseg_event_query(int64_t ev);
  * parameter that received no gradient: torch.optim's zero_grad at ref semi_seg/epocher.py:177). */
 int miseg_fill_zero(void* stream, void* dst, int64_t nbytes);
 int miseg_copy(void* stream, void* dst, const void* src, int64_t nbytes);
+/* dst[o][j][0..chunk) = src[o][idx[j]][0..chunk) for o < outer, j < n_idx (fp32; idx = int32 device array of rows < n_src): the windows
+ * of one colour group picked out of a per-window tensor -- overlapping patches (ref iic_loss.py:152-189) are differentiated in
+ * pairwise-disjoint groups, one launch each. */
+int miseg_gather_rows(void* stream, const float* src, float* dst, int64_t outer, int64_t n_src, int64_t n_idx, const int32_t* idx,
+                      int64_t chunk);
 /* Gradient of the logits batch [labeled | unlabeled | flipped unlabeled] (ref semi_seg/epocher.py:154-159 splits it, autograd
  * scales each loss's gradient by its coefficient, zero-fills the detached part and concatenates): out = [scale0[0] * src0 |
  * scale1[0] * src1 | scale2[0] * src2], fp32, a null src = zeros, a null scale = 1; numel_i multiples of 4. */
@@ -288,6 +293,10 @@ int miseg_flip(void* stream, const void* in, void* out, int64_t N, int64_t C, in
  * ref semi_seg/epocher.py:148-153 (stack of per-sample flips, then torch.cat of labeled, unlabeled, transformed unlabeled). */
 int miseg_cat_flip(void* stream, const void* a, int64_t Na, const void* b, int64_t Nb, int64_t C, int64_t H, int64_t W,
                    const int32_t* flips, void* out);
+/* the same for ONE-channel fp32 images, writing besides `out` the stem's operand: pad8 = dt_pad [N][H][W][8], channel 0 = the pixel
+ * rounded to dt_pad (MISEG_BF16 / MISEG_F16), channels 1..7 zero -- what miseg_cast_pad would make of `out` (unet.py:15, Conv1's input). */
+int miseg_cat_flip_pad(void* stream, const float* a, int64_t Na, const float* b, int64_t Nb, int64_t H, int64_t W,
+                       const int32_t* flips, float* out, int dt_pad, void* pad8);
 /* argmax over channels + per-sample per-class intersection/union counts (int64 [N][C] each);
  * ref semi_seg/epocher.py:183 + whl:.../general_dice_meter.py:141-172. pred (int64 [N,H,W]) optional. */
 int miseg_argmax_dice(void* stream, const float* logits, const int64_t* labels, int64_t N, int64_t H, int64_t W,
@@ -410,6 +419,12 @@ int miseg_bn_relu_bwd_dual(void* stream, int dt, const void* raw, const void* gy
                            int64_t n2_begin, int64_t n2_end, int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma,
                            const float* saved, int training, void* graw, float* ggamma, float* gbeta, void* ws,
                            int64_t ws_bytes);
+/* bn_relu_bwd WITHOUT its reduce pass: the per-block sums of dz and dz * xhat come from the epilogue of the convolution that wrote gy
+ * (miseg_conv3x3_dgrad_bn called with red_raw / red_saved / red_parts and a plain graw input): finalize from ext_parts
+ * [ext_nparts][2][C], then the apply pass.  Layers without the fused pool; ws >= 3 C floats. */
+int miseg_bn_relu_bwd_ext(void* stream, int dt, const void* raw, const void* gy, int64_t N, int64_t H, int64_t W, int64_t C,
+                          const float* gamma, const float* saved, int training, void* graw, float* ggamma, float* gbeta,
+                          const float* ext_parts, int64_t ext_nparts, void* ws, int64_t ws_bytes);
 /* BatchNorm backward folded into the convolutions around it (ref: unet.py:14-21, 31-36 -- what autograd runs as
  * threshold_backward -> native_batch_norm_backward -> convolution_backward becomes two launches per layer):
  *   bn_relu_bwd_stats : the statistics half of bn_relu_bwd for a layer WITHOUT the fused pool: ggamma, gbeta and

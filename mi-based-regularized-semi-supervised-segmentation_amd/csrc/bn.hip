@@ -581,6 +581,35 @@ extern "C" int miseg_bn_relu_bwd_dual(void* stream, int dt, const void* raw, con
     return bn_relu_bwd_impl(stream, dt, raw, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, nullptr, nullptr, gy2, n2_begin, n2_end);
 }
 
+// finalize + apply only: the per-block sums (sum dz, sum dz * xhat) were taken by the epilogue of the data-gradient convolution that
+// wrote gy (miseg_conv3x3_dgrad_bn with red_*): the reduce pass over (raw, gy) is not run.  ws: 3 C floats.
+extern "C" int miseg_bn_relu_bwd_ext(void* stream, int dt, const void* raw, const void* gy, int64_t N, int64_t H, int64_t W, int64_t C,
+                                     const float* gamma, const float* saved, int training, void* graw, float* ggamma, float* gbeta,
+                                     const float* ext_parts, int64_t ext_nparts, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_bn_relu_bwd_ext, stream, dt, raw, gy, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ext_parts, ext_nparts, ws, ws_bytes);
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_ext, stream, MISEG_BF16, raw, gy, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ext_parts,
+                          ext_nparts, ws, ws_bytes);
+    MISEG_REQUIRE(raw && gy && gamma && saved && graw && ggamma && gbeta && ext_parts && ext_nparts > 0 && ws && ws_bytes >= 3 * C * 4, "bn_relu_bwd_ext: bad args");
+    const int V = dt == MISEG_BF16 ? 8 : 4;
+    const int CV = (int)(C / V);
+    MISEG_REQUIRE(dt != MISEG_F16 && C % V == 0 && 256 % CV == 0, "bn_relu_bwd_ext: C/%d must divide 256", V);
+    hipStream_t st = as_stream(stream);
+    const int64_t npix = N * H * W;
+    float* coeffs = (float*)ws;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, ext_parts, (int)ext_nparts, (int)C, (float)npix, gamma, saved, training,
+                       coeffs, ggamma, gbeta, (float*)nullptr);
+    MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    const int na = ew_blocks(npix * CV);
+    if (dt == MISEG_F32)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(na), dim3(256), 0, st, (const float*)raw, (const float*)gy, (const float*)nullptr, (int)N,
+                           (int)H, (int)W, (int)C, saved, coeffs, (float*)graw, BnGy2<float>{nullptr, 0, 0});
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, false>), dim3(na), dim3(256), 0, st, (const bf16*)raw, (const bf16*)gy, (const bf16*)nullptr, (int)N,
+                           (int)H, (int)W, (int)C, saved, coeffs, (bf16*)graw, BnGy2<bf16>{nullptr, 0, 0});
+    MISEG_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return MISEG_OK;
+}
+
 extern "C" int miseg_bn_relu_bwd_stats(void* stream, int dt, const void* raw, const void* gy, int64_t N, int64_t H, int64_t W, int64_t C,
                                        const float* gamma, const float* saved, int training, float* bwd_coef, float* ggamma, float* gbeta,
                                        const float* ext_parts, int64_t ext_nparts, void* ws, int64_t ws_bytes) {

@@ -1,6 +1,8 @@
 // Pixel-wise losses on fp32 NHWC logits, the per-sample flip, argmax + Dice counts.
 // All HBM-bound streaming kernels: one pixel per thread, channel vector in registers, two-pass
 // deterministic sums (per-block partial -> single-block finish).
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace miseg {
@@ -379,6 +381,47 @@ __global__ __launch_bounds__(256) void cat_flip_kernel(const uint32_t* __restric
     }
 }
 }  // namespace miseg
+// ... and, for one-channel images, the stem's operand in the same pass: pad[n][h][w][0] = 16-bit value, channels 1..7 zero (what
+// miseg_cast_pad makes of `out`), so the network's first convolution starts from this kernel's output
+namespace miseg {
+template <bool HALF>
+__global__ __launch_bounds__(256) void cat_flip_pad_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                          uint4* __restrict__ pad, int Na, int Nb, int H, int W, const int32_t* __restrict__ flips) {
+    const int64_t per = (int64_t)H * W, total = (int64_t)(Na + 2 * Nb) * per;
+    for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e / per, r = e - n * per;
+        float v;
+        if (n < Na) v = a[e];
+        else if (n < Na + Nb) v = b[e - (int64_t)Na * per];
+        else {
+            const int m = (int)(n - Na - Nb), f = flips[m];
+            const int w = r % W, h = r / W;
+            const int hs = (f & 1) ? H - 1 - h : h, wsrc = (f & 2) ? W - 1 - w : w;
+            v = b[(int64_t)m * per + (int64_t)hs * W + wsrc];
+        }
+        out[e] = v;
+        unsigned bits;
+        if (HALF) bits = (unsigned)__half_as_ushort(__float2half(v));
+        else { const __hip_bfloat16 hb = __float2bfloat16(v); bits = (unsigned)*reinterpret_cast<const unsigned short*>(&hb); }
+        pad[e] = make_uint4(bits, 0u, 0u, 0u);
+    }
+}
+}  // namespace miseg
+extern "C" int miseg_cat_flip_pad(void* stream, const float* a, int64_t Na, const float* b, int64_t Nb, int64_t H, int64_t W, const int32_t* flips,
+                                  float* out, int dt_pad, void* pad8) {
+    MISEG_TAPE(miseg_cat_flip_pad, stream, a, Na, b, Nb, H, W, flips, out, dt_pad, pad8);
+    MISEG_REQUIRE(out && pad8 && flips && (a || Na == 0) && b && Na >= 0 && Nb > 0 && H > 0 && W > 0, "cat_flip_pad: bad args");
+    MISEG_REQUIRE(dt_pad == MISEG_BF16 || dt_pad == MISEG_F16, "cat_flip_pad: the padded copy is a 16-bit type");
+    const int64_t total = (Na + 2 * Nb) * H * W;
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv(total, 256), 8192));
+    if (dt_pad == MISEG_F16)
+        hipLaunchKernelGGL(cat_flip_pad_kernel<true>, grid, dim3(256), 0, as_stream(stream), a, b, out, (uint4*)pad8, (int)Na, (int)Nb, (int)H, (int)W, flips);
+    else
+        hipLaunchKernelGGL(cat_flip_pad_kernel<false>, grid, dim3(256), 0, as_stream(stream), a, b, out, (uint4*)pad8, (int)Na, (int)Nb, (int)H, (int)W, flips);
+    MISEG_LAUNCH_CHECK("cat_flip_pad_kernel");
+    return MISEG_OK;
+}
+
 extern "C" int miseg_cat_flip(void* stream, const void* a, int64_t Na, const void* b, int64_t Nb, int64_t C, int64_t H, int64_t W,
                               const int32_t* flips, void* out) {
     MISEG_TAPE(miseg_cat_flip, stream, a, Na, b, Nb, C, H, W, flips, out);
@@ -397,8 +440,11 @@ extern "C" int miseg_argmax_dice(void* stream, const float* logits, const int64_
     MISEG_REQUIRE(!labels || (inter && uni), "argmax_dice: labels need inter/uni outputs");
     hipStream_t st = as_stream(stream);
     if (labels) {
-        hipMemsetAsync(inter, 0, (size_t)N * C * 8, st);
-        hipMemsetAsync(uni, 0, (size_t)N * C * 8, st);
+        if (uni == inter + N * C) hipMemsetAsync(inter, 0, (size_t)N * C * 16, st);      // adjacent (the iteration's read-back block): one fill
+        else {
+            hipMemsetAsync(inter, 0, (size_t)N * C * 8, st);
+            hipMemsetAsync(uni, 0, (size_t)N * C * 8, st);
+        }
     }
     dim3 grid((unsigned)std::min<int64_t>(cdiv(H * W, 256), 64), (unsigned)N);
 #define L(CC) hipLaunchKernelGGL(argmax_dice_kernel<CC>, grid, dim3(256), 0, st, logits, labels, (int)(H * W), pred, (unsigned long long*)inter, (unsigned long long*)uni)

@@ -300,6 +300,29 @@ __global__ void __launch_bounds__(256) assemble_rows_kernel(float4* __restrict__
 }
 }  // namespace miseg
 
+namespace miseg {
+// dst[o][j][:] = src[o][idx[j]][:] (rows of `chunk` floats): the windows of one colour group picked out of a per-window tensor
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t outer, int64_t n_src, int64_t n_idx,
+                                                          const int32_t* __restrict__ idx, int64_t chunk) {
+    const int64_t total = outer * n_idx * chunk, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e % chunk, j = (e / chunk) % n_idx, o = e / (chunk * n_idx);
+        dst[e] = src[(o * n_src + idx[j]) * chunk + r];
+    }
+}
+}  // namespace miseg
+
+extern "C" int miseg_gather_rows(void* stream, const float* src, float* dst, int64_t outer, int64_t n_src, int64_t n_idx, const int32_t* idx,
+                                 int64_t chunk) {
+    MISEG_TAPE(miseg_gather_rows, stream, src, dst, outer, n_src, n_idx, idx, chunk);
+    MISEG_REQUIRE(src && dst && idx && outer > 0 && n_src > 0 && n_idx > 0 && chunk > 0, "gather_rows: bad args");
+    const int64_t total = outer * n_idx * chunk;
+    hipLaunchKernelGGL(miseg::gather_rows_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 4096))), dim3(256), 0,
+                       miseg::as_stream(stream), src, dst, outer, n_src, n_idx, idx, chunk);
+    MISEG_LAUNCH_CHECK("gather_rows_kernel");
+    return MISEG_OK;
+}
+
 static inline int ew_blocks(int64_t n16) { return (int)std::max<int64_t>(1, std::min<int64_t>((n16 + 255) / 256, 2048)); }
 
 extern "C" int miseg_fill_zero(void* stream, void* dst, int64_t nbytes) {

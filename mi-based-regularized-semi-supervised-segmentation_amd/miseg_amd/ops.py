@@ -332,8 +332,14 @@ class _LocalMIHeads(torch.autograd.Function):
                 if len(grp) == len(ctx.windows):
                     gwin, ggrad, gscale = win, grad_raw, scale
                 else:
-                    idx = cached_const(("idx", str(probs.device), tuple(grp)), lambda: torch.tensor(grp, dtype=torch.long, device=probs.device))
-                    gwin, ggrad, gscale = win[idx].contiguous(), grad_raw[:, idx].contiguous(), scale[:, idx].contiguous()
+                    dev = probs.device
+                    idx = cached_const(("idx32", str(dev), tuple(grp)), lambda: torch.tensor(grp, dtype=torch.int32, device=dev))
+                    gwin = cached_const(("gwin", str(dev), tuple(ctx.windows), tuple(grp)), lambda: win[idx.long()].contiguous())
+                    npw, per = len(ctx.windows), grad_raw[0, 0].numel()
+                    ggrad = torch.empty((s, len(grp)) + tuple(grad_raw.shape[2:]), dtype=torch.float32, device=dev)
+                    gscale = torch.empty((s, len(grp)), dtype=torch.float32, device=dev)
+                    call("miseg_gather_rows", _stream(), _ptr(grad_raw), _ptr(ggrad), s, npw, len(grp), _ptr(idx), per)
+                    call("miseg_gather_rows", _stream(), _ptr(scale), _ptr(gscale), s, npw, len(grp), _ptr(idx), 1)
                 px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
                 call("miseg_iic_local_bwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, ctx.pad, _ptr(gwin), len(grp), _ptr(ggrad),
                      _ptr(gscale), _ptr(gprob), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(),
@@ -1022,12 +1028,19 @@ def split_rows(x: Tensor, sizes) -> tuple:
     return outs
 
 
-def cat_flip(a: Tensor, b: Tensor, flips: Tensor) -> Tensor:
-    """``torch.cat([a, b, flip(b)])`` along dim 0 in one launch (ref semi_seg/epocher.py:148-153: the network's input batch)."""
+def cat_flip(a: Tensor, b: Tensor, flips: Tensor, stem_dtype=None) -> Tensor:
+    """``torch.cat([a, b, flip(b)])`` along dim 0 in one launch (ref semi_seg/epocher.py:148-153: the network's input batch).
+    ``stem_dtype`` (bfloat16 / float16, one-channel fp32 images): the same launch also writes the first convolution's operand -- the
+    batch cast to that type and padded to one channel vector -- and hangs it on the result (``_miseg_stem``) for ``unet_ops.stem_input``."""
     _need_gpu(a, b, flips)
     a, b = a.contiguous(), b.contiguous()
     assert a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and a.element_size() == 4 and a.dim() == 4, (a.shape, b.shape, a.dtype)
     na, nb = a.shape[0], b.shape[0]
     out = torch.empty((na + 2 * nb,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    if stem_dtype in (torch.bfloat16, torch.float16) and a.dtype == torch.float32 and a.shape[1] == 1:
+        pad = empty_nhwc(na + 2 * nb, 8, a.shape[2], a.shape[3], stem_dtype, a.device)
+        call("miseg_cat_flip_pad", _stream(), _ptr(a), na, _ptr(b), nb, a.shape[2], a.shape[3], _ptr(flips), _ptr(out), _DT[stem_dtype], _ptr(pad))
+        out._miseg_stem = (stem_dtype, pad)
+        return out
     call("miseg_cat_flip", _stream(), _ptr(a), na, _ptr(b), nb, a.shape[1], a.shape[2], a.shape[3], _ptr(flips), _ptr(out))
     return out

@@ -60,6 +60,8 @@ _DUAL_DGRAD = True       # concat layers: one data-gradient launch with two dest
 # epilogue (no bn_relu_bwd_reduce pass there).  OFF by default (MISEG_BN_FUSE=1 turns it on): measured slower, DESIGN.md section 9.
 _FUSE_BN_BWD = os.environ.get("MISEG_BN_FUSE", "0") == "1"
 _FUSE_BN_RED = True      # ... including the statistics pass in the producing data-gradient kernel's epilogue
+# The statistics pass ALONE in the producing data-gradient kernel's epilogue (no loader transform): MISEG_BN_RED=1 (round-4 experiment)
+_RED_ONLY = os.environ.get("MISEG_BN_RED", "0") == "1" and not _FUSE_BN_BWD
 
 
 class _BnRec:
@@ -147,6 +149,9 @@ def vec_of(dtype) -> int:
 def stem_input(image: Tensor, dtype) -> Tensor:
     """fp32 [B,Cin,H,W] image -> [B,VEC,H,W] channels_last tensor of ``dtype`` (extra channels zero)."""
     _need_gpu(image)
+    pre = getattr(image, "_miseg_stem", None)      # the launch that assembled the batch wrote this operand too (ops.cat_flip)
+    if pre is not None and pre[0] == dtype and pre[1].shape[0] == image.shape[0]:
+        return pre[1]
     b, cin, h, w = image.shape
     image = as_nhwc(image.float())
     cp = vec_of(dtype)
@@ -350,7 +355,12 @@ class _ConvBNReLU(torch.autograd.Function):
         if gbeta is None:
             gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
-        if extra is not None:
+        if ext_parts is not None and not extras and gpool is None and gy is not None and not want_pool and dtype != torch.float16:
+            # the data-gradient kernel that wrote gy has summed dz and dz * xhat per block in its epilogue: finalize + apply only
+            call("miseg_bn_relu_bwd_ext", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), n, h, w, cout, _ptr(gamma), _ptr(saved), int(training),
+                 _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ext_parts), ext_nparts, _ptr(ws), ws.numel(),
+                 work=(0.0, float(raw.element_size()) * n * h * w * cout * 3.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
+        elif extra is not None:
             g2, n0, n1, _ = extra
             g2 = as_nhwc(g2)
             call("miseg_bn_relu_bwd_dual", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), _ptr(gpool), _ptr(g2), n0, n1, n, h, w, cout, _ptr(gamma),
@@ -406,7 +416,7 @@ class _ConvBNReLU(torch.autograd.Function):
         grads = [None, None]
         from .ops import _GradJoin
         if _DUAL_DGRAD and x1 is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ups0 and not ups1 and \
-                c0 % 16 == 0 and c1 % 4 == 0 and not _GradJoin.enabled and not (_FUSE_BN_BWD and _FUSE_BN_RED):
+                c0 % 16 == 0 and c1 % 4 == 0 and not _GradJoin.enabled and not (_FUSE_BN_BWD and _FUSE_BN_RED) and not _RED_ONLY:
             # concat of two full-resolution sources: both data gradients in ONE launch (graw read once, twice the blocks)
             packed = _pack(weight, dtype, 1, 0, c0 + c1)
             g0, g1 = empty_nhwc(n, c0, h, w, dtype, dev), empty_nhwc(n, c1, h, w, dtype, dev)
@@ -551,7 +561,7 @@ def _dgrads_fusable(ctx, dtype) -> bool:
 
 def _red_target(src_rec: Optional[_BnRec], ups: int, dtype, cout: int, n: int, h: int, w: int, cs: int):
     """(parts, nparts) if this data-gradient launch can take the source layer's BatchNorm-backward sums in its epilogue."""
-    if not (_FUSE_BN_BWD and _FUSE_BN_RED) or src_rec is None or ups or src_rec.raw is None or src_rec.shape != (n, cs, h, w) or \
+    if not ((_FUSE_BN_BWD and _FUSE_BN_RED) or _RED_ONLY) or src_rec is None or ups or src_rec.raw is None or src_rec.shape != (n, cs, h, w) or \
             src_rec.raw.dtype != dtype:
         return None
     nparts = query("miseg_conv3x3_dgrad_red_parts", _DT[dtype], cout, n, h, w, cs)
@@ -565,7 +575,7 @@ def conv_bn_relu(x0: Tensor, x1: Optional[Tensor], weight: Tensor, gamma: Tensor
                  want_pool: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     # the hand-over record exists only where it can be used: the opt-in fused backward, a layer without the fused pool (a pooled layer's
     # backward routes through the 2x2 windows and keeps its own reduce), a forward pass that records a graph
-    rec = _BnRec() if (_FUSE_BN_BWD and _FUSE_BN_RED and not want_pool and torch.is_grad_enabled()) else None
+    rec = _BnRec() if (((_FUSE_BN_BWD and _FUSE_BN_RED) or _RED_ONLY) and not want_pool and torch.is_grad_enabled()) else None
     rec0 = getattr(x0, "_miseg_bn", None) if not ups0 else None
     rec1 = getattr(x1, "_miseg_bn", None) if x1 is not None and not ups1 else None
     sink = _GradSink() if torch.is_grad_enabled() and not _FUSE_BN_BWD else None

@@ -421,7 +421,9 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         if labeled_image.dtype == unlabeled_image.dtype == torch.float32 and labeled_image.dim() == 4 and \
                 labeled_image.shape[1:] == unlabeled_image.shape[1:] and labeled_image.is_cuda:
             # [labeled | unlabeled | flip(unlabeled)] in one launch (ref :148-153: per-sample flips, stack, cat)
-            batch = ops.cat_flip(labeled_image, unlabeled_image, flips)
+            net = getattr(self._model, "module", self._model)
+            batch = ops.cat_flip(labeled_image, unlabeled_image, flips,
+                                 stem_dtype=getattr(net, "compute_dtype", None) if getattr(net, "input_dim", None) == 1 else None)
             unlabeled_image_tf = batch[lb + ub:]
         else:
             unlabeled_image_tf = ops.flip(unlabeled_image, flips)
