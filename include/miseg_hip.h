@@ -346,6 +346,9 @@ int miseg_conv3x3_wgrad_slice(void* stream, const float* gw_padded, int64_t Cout
 int miseg_pack_conv3x3_weights_multi(void* stream, int dt, const void* jobs_dev, int64_t njobs, int64_t total_blocks);
 /* number of per-block (sum, sumsq) partial rows conv3x3_fwd writes: stats_partials = fp32[parts][2][Cout] */
 int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W);
+/* ... of miseg_conv3x3_fwd proper (one row per block of the kernel that serves the shape; <= miseg_conv3x3_stats_parts, which stays the
+ * row count of miseg_conv3x3_bn_fwd and of the epilogue reduce of miseg_conv3x3_dgrad_bn) */
+int64_t miseg_conv3x3_fwd_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout);
 int miseg_conv3x3_fwd(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1,
                       int ups1, int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out,
                       float* stats_partials);

@@ -336,6 +336,215 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvSrc src, int N,
     }
 }
 
+// Persistent form of conv3x3_kernel for 16-bit storage (plain forms: no BatchNorm loader / epilogue reduce / last-block finish).
+// conv3x3_kernel spends most of a block's life outside the matrix cores: a 64^2 layer with 32 input channels is ONE chunk per tile, so
+// the first (and only) global fetch, the two barriers, the epilogue stores and the 2 x NT x 4 x 4-shuffle statistics reduction are all
+// exposed, once per tile, three to six block generations per CU (profiles/r04a_bench_bf16_kernel_stats.csv: 1.06 ms per step at 15-26 %
+// of the matrix peak).  Here a block owns a CONTIGUOUS run of tiles of one output-channel slice and software-pipelines across them:
+//   * while the LAST chunk of tile i is on the matrix cores, chunk 0 of tile i + 1 (haloed input + weights) is already in flight in
+//     registers, so the epilogue of tile i (stores, statistics) runs under that fetch instead of in front of it;
+//   * BatchNorm statistics are kept per lane across the block's tiles and reduced once per block (one partial row per block:
+//     parts = gridDim.x, which also shrinks what bn_finalize has to read);
+//   * consecutive tiles of a block are spatial neighbours (their halos hit the XCD's L2 while still warm) and share the weight slice.
+// Arithmetic, tile shape, LDS layout and epilogues are those of conv3x3_kernel; only the summation order of the statistics differs
+// (per block over its tiles instead of per tile).
+template <typename T, int COT, int TW, int THT, bool POOL, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
+                                                           T* __restrict__ out, float* __restrict__ stats, BnFinish fin, int ntiles, int per) {
+    static_assert(sizeof(T) == 2, "persistent tiled form: 16-bit storage types");
+    typedef Mma<T> MM;
+    constexpr int kCT = 64 * NW;
+    static_assert(THT % NW == 0, "whole rows per wave");
+    constexpr int VEC = MM::VEC, NT = COT / 16, MTR = TW / 16, RW = THT / NW, MTW = RW * MTR;
+    constexpr int KP = MM::KP;
+    constexpr int IW = TW + 2, IH = THT + 2;
+    constexpr int NIS = (IH * IW * (CK / VEC) + kCT - 1) / kCT, NWS = (9 * COT * (CK / VEC) + kCT - 1) / kCT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* Is = reinterpret_cast<T*>(smem);                    // [IH][IW][KP]
+    T* Ws = Is + IH * IW * KP;                             // [9][COT][KP]
+    const int Cin = src.C0 + src.C1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int tilesC = (W + TW - 1) / TW, tilesR = (H + THT - 1) / THT;
+    const int co0 = blockIdx.y * COT;
+    const int t_begin = blockIdx.x * per, t_end = min(t_begin + per, ntiles);
+
+    uint4 pin[NIS], pwt[NWS];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    auto fetch = [&](int n, int h0, int w0, int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NIS; ++j) {
+            const int idx = tid + kCT * j;
+            const int v = idx % (CK / VEC), px = idx / (CK / VEC), ix = px % IW, iy = px / IW;
+            const int h = h0 - 1 + iy, w = w0 - 1 + ix, c = c0 + v * VEC;
+            uint4 val = zero4;
+            if (idx < IH * IW * (CK / VEC) && h >= 0 && h < H && w >= 0 && w < W && c < Cin) {
+                const T* sp;
+                if (c < src.C0) {
+                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
+                    sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
+                } else {
+                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
+                    sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
+                }
+                val = *reinterpret_cast<const uint4*>(sp);
+            }
+            pin[j] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < NWS; ++j) {
+            const int idx = tid + kCT * j;
+            const int v = idx % (CK / VEC), co = (idx / (CK / VEC)) % COT, tap = idx / ((CK / VEC) * COT);
+            const int c = c0 + v * VEC;
+            uint4 val = zero4;
+            if (idx < 9 * COT * (CK / VEC) && co0 + co < Cout && c < Cin)
+                val = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
+            pwt[j] = val;
+        }
+    };
+    const T* Ib = Is + ((wv * RW) * IW + l15) * KP;
+    const T* Wb = Ws + l15 * KP;
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
+
+    // tile coordinates are block-uniform: decoded once per tile (scalar unit), never inside the fetch
+    int nn = 0, nh0 = 0, nw0 = 0;
+    if (t_begin < t_end) {
+        nn = t_begin / (tilesC * tilesR); nh0 = ((t_begin / tilesC) % tilesR) * THT; nw0 = (t_begin % tilesC) * TW;
+        fetch(nn, nh0, nw0, 0);
+    }
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int n = nn, h0 = nh0, w0 = nw0;
+        const bool more = tile + 1 < t_end;
+        if (more) { const int t1 = tile + 1; nn = t1 / (tilesC * tilesR); nh0 = ((t1 / tilesC) % tilesR) * THT; nw0 = (t1 % tilesC) * TW; }
+        f32x4 acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < Cin; c0 += CK) {
+            __syncthreads();                       // the previous chunk's MFMAs are done with Is / Ws
+#pragma unroll
+            for (int j = 0; j < NIS; ++j) {
+                const int idx = tid + kCT * j;
+                if (idx < IH * IW * (CK / VEC)) *reinterpret_cast<uint4*>(Is + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pin[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NWS; ++j) {
+                const int idx = tid + kCT * j;
+                if (idx < 9 * COT * (CK / VEC)) *reinterpret_cast<uint4*>(Ws + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pwt[j];
+            }
+            __syncthreads();
+            {   // ONE fetch site: the next chunk of this tile, or -- across the tile boundary, in flight under this tile's epilogue --
+                const bool last = c0 + CK >= Cin;                    // chunk 0 of the next tile
+                if (!last || more) fetch(last ? nn : n, last ? nh0 : h0, last ? nw0 : w0, last ? 0 : c0 + CK);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                typename MM::Frag bf[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bf[t] = MM::load(Wb + (tap * COT + t * 16) * KP, kq);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    typename MM::Frag af = MM::load(Ib + ((m / MTR + ky) * IW + (m % MTR) * 16 + kx) * KP, kq);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);   // D^T: rows = channels, cols = pixels
+                }
+            }
+        }
+        // ---- epilogue of this tile (conv3x3_kernel's): a lane owns 4 consecutive channels of one pixel
+        if (POOL) {
+            static_assert(!POOL || RW % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
+            const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+            for (int mp = 0; mp < MTW / 2; ++mp) {
+                const int m0 = (2 * (mp / MTR)) * MTR + mp % MTR, m1 = m0 + MTR;
+                const int hp = ((h0 + wv * RW) >> 1) + mp / MTR, wp = ((w0 + (mp % MTR) * 16) >> 1) + (l15 >> 1);
+                const bool mine = !(l15 & 1) && hp < Hp && wp < Wp;
+                T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int co = co0 + t * 16 + kq * 4;
+                    T pk[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[m0][t][r] + acc[m1][t][r];
+                        v += __shfl_xor(v, 1, 64);
+                        pk[r] = from_f32<T>(v);
+                    }
+                    if (!mine) continue;
+                    if (co + 3 < Cout) *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < Cout) op[co + r] = pk[r];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+                const bool ok = h < H && w < W;
+                const size_t px = ((size_t)n * H + h) * W + w;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int co = co0 + t * 16 + kq * 4;
+                    T* op = out + px * Cout;
+                    if (fin.out1) op = co < fin.split ? out + px * fin.split : reinterpret_cast<T*>(fin.out1) + px * (Cout - fin.split) - fin.split;
+                    if (ok && co + 3 < Cout) {
+                        T pk[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[m][t][r];
+                            pk[r] = from_f32<T>(v);
+                            s1[t][r] += v;
+                            s2[t][r] += v * v;
+                        }
+                        *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                    } else if (ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < Cout) {
+                                const float v = acc[m][t][r];
+                                op[co + r] = from_f32<T>(v);
+                                s1[t][r] += v;
+                                s2[t][r] += v * v;
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (!POOL && stats) {          // one partial row per block (a block without tiles writes zeros)
+        __shared__ float sred[NW][2][COT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s1[t][r], b = s2[t][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    a += __shfl_xor(a, off, 64);
+                    b += __shfl_xor(b, off, 64);
+                }
+                if (l15 == 0) { sred[wv][0][t * 16 + kq * 4 + r] = a; sred[wv][1][t * 16 + kq * 4 + r] = b; }
+            }
+        __syncthreads();
+        if (tid < COT && co0 + tid < Cout) {
+            float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
+            float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+#pragma unroll
+            for (int q = 4; q < NW; ++q) { a += sred[q][0][tid]; b += sred[q][1][tid]; }
+            stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
+            stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
+        }
+    }
+}
+
 // Streaming variant for the HBM-bound layers (Cin <= 32, bf16): persistent blocks walk tiles; the next tile's haloed input
 // (NVEC 16-byte channel vectors per pixel) is fetched into registers while the current tile is on the matrix cores, and the
 // weight chunk is staged once per block.  Same arithmetic, tile shape and output as conv3x3_kernel.  These layers are
@@ -1356,6 +1565,19 @@ static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
     return std::min<int64_t>(N * cdiv(H, TH) * cdiv(W, 32), cap);
 }
 
+// Grid of the persistent tiled kernel: `blocks` x-blocks of `per` consecutive tiles each (none empty), sized so that blocks.x * slices
+// fills the chip once: two blocks per CU for the 8-row tiles (60 KB of LDS each), one for the 16-row tiles.
+struct PtGrid { int blocks, per; };
+static inline PtGrid pt_grid(int ntiles, int slices, int th) {
+    const int target = std::max(1, (256 * (th == 8 ? 2 : 1)) / std::max(1, slices));
+    const int per = std::max(1, (ntiles + target - 1) / target);
+    return PtGrid{(ntiles + per - 1) / per, per};
+}
+static inline bool tiled_persistent() {
+    static const bool on = [] { const char* e = getenv("MISEG_CONV_PERSISTENT"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 // tile height of the generic kernel (bf16): 8 rows from 64^2 upwards (smaller LDS tile -> two blocks per CU; measured
 // 128^2 64->32: 78 -> 64 us), 16 rows for the small deep layers (32^2: 8-row tiles cost 46 -> 55 us) and for exact fp32
 static int generic_tile_h(int dt, int64_t H, int64_t W) {
@@ -1370,6 +1592,18 @@ extern "C" int64_t miseg_conv3x3_stats_parts(int dt, int64_t Cin, int64_t N, int
     return N * cdiv(H, generic_tile_h(dt, H, W)) * cdiv(W, tw);
 }
 
+// Rows of the statistics matrix miseg_conv3x3_fwd writes for this layer (what bn_finalize must be told): one per block of the kernel
+// that serves the shape -- the persistent tiled kernel has far fewer blocks than tiles.
+extern "C" int64_t miseg_conv3x3_fwd_parts(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_parts, MISEG_BF16, Cin, N, H, W, Cout);
+    const int64_t ntiles = miseg_conv3x3_stats_parts(dt, Cin, N, H, W);
+    if (conv_streams(dt, Cin, N, H, W) || dt != MISEG_BF16 || !tiled_persistent()) return ntiles;
+    const int th = generic_tile_h(dt, H, W);
+    if (th != 8) return ntiles;                                                          // (launch_tiled: the persistent form serves 8-row tiles)
+    const int64_t cot = Cout <= 16 ? 16 : 32;                                           // conv3x3_fwd_impl's slice width for 8-row tiles
+    return pt_grid((int)ntiles, (int)cdiv(Cout, cot), th).blocks;
+}
+
 // pooled-output forms exist for the streaming shapes and, in the tiled kernel, for 16-bit storage with more than 32 output channels
 static bool sumpool_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
     if (H % 2 || W % 2) return false;
@@ -1382,6 +1616,20 @@ template <typename TT, int COT, int TWW, int THH, bool POOL>
 static void launch_tiled(dim3 grid, hipStream_t st, const ConvSrc& s, int N, int H, int W, const void* wpk, int Cout, void* out, float* stats,
                          const BnFinish& fin, const BnLoad& bl, const BnRed& br) {
     const size_t lb = ((size_t)(THH + 2) * (TWW + 2) + 9 * COT) * Mma<TT>::KP * sizeof(TT);
+    if constexpr (sizeof(TT) == 2) {
+        // the plain forms of the 8-row tiles (maps from 64^2 up: several tiles per block): persistent blocks, pipelined across tiles.
+        // Measured per launch, same box (gpurun_out/prof_pt*): 32-channel slices 48.1 -> 38.7 us, pooled 64-channel 75.5 -> 67.6; the
+        // 16-row tiles of the deep layers have one tile per block either way and ran 4-29 % slower in this form -> they keep the other
+        if (THH == 8 && !bl.gy && !br.raw && !fin.counter && tiled_persistent()) {
+            const int ntiles = (int)grid.x;
+            const PtGrid g = pt_grid(ntiles, (int)grid.y, THH);
+            constexpr int NWW = (THH == 16) ? 8 : 4;
+            hipFuncSetAttribute((const void*)conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW>), dim3((unsigned)g.blocks, grid.y), dim3(64 * NWW), lb, st, s, N, H, W,
+                               (const TT*)wpk, Cout, (TT*)out, stats, fin, ntiles, g.per);
+            return;
+        }
+    }
 #define GO(BNL, RED, NWW)                                                                                                            \
     {                                                                                                                               \
         hipFuncSetAttribute((const void*)conv3x3_kernel<TT, COT, TWW, THH, POOL, BNL, RED, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); \

@@ -287,14 +287,15 @@ class _ConvBNReLU(torch.autograd.Function):
         packed = _pack(weight, dtype, 0, cin=c0 + c1)
         raw = empty_nhwc(n, cout, h, w, dtype, dev)
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
-        if training:
-            parts = query("miseg_conv3x3_stats_parts", _DT[dtype], c0 + c1, n, h, w)
+        counter = SYNC_COUNTERS.take(dev) if training and query("miseg_conv3x3_bn_fwd_fusable", _DT[dtype], c0 + c1, n, h, w, cout) else None
+        if training:       # rows of the statistics matrix: one per block of the kernel that will serve this shape
+            parts = query("miseg_conv3x3_stats_parts", _DT[dtype], c0 + c1, n, h, w) if counter is not None else \
+                query("miseg_conv3x3_fwd_parts", _DT[dtype], c0 + c1, n, h, w, cout)
             stats = torch.empty(parts * 2 * cout, dtype=torch.float32, device=dev)
         else:
             parts, stats = 0, None
         es = x0.element_size()
         work = (18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout))
-        counter = SYNC_COUNTERS.take(dev) if training and query("miseg_conv3x3_bn_fwd_fusable", _DT[dtype], c0 + c1, n, h, w, cout) else None
         if counter is not None:     # the conv's last block turns the partial sums into `saved` / the running statistics itself
             call("miseg_conv3x3_bn_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
                  _ptr(stats), _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved),
