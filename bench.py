@@ -126,11 +126,21 @@ def cpu_baseline(threads):
     OS.train_step(state, lab, tgt, unl, seed=999, mode="udaiic")
     dt2 = time.time() - t0
     out["cfg2_shape"] = {"value": round(2 * big / dt2, 4), "unit": "images/s", "sample": f"1 udaiic train step at LB=UB={big}, 256x256, fp32, {dt2:.1f} s"}
+    # BASELINE configs[0] as it stands: the `partial` (supervised-only) trainer, batch 2, num_batches 4 -- the reference's own CPU-runnable case
+    state1 = OS.StepState(OU.init_state(1, 4, seed=5), {}, lr=4e-5, weight_decay=1e-5)
+    lab, tgt = torch.rand(2, 1, 256, 256, generator=g), torch.randint(0, 4, (2, 1, 256, 256), generator=g)
+    unl = torch.rand(2, 1, 256, 256, generator=g)
+    OS.train_step(state1, lab, tgt, unl, seed=7, mode="partial")
+    t0 = time.time()
+    for i in range(4):
+        OS.train_step(state1, lab, tgt, unl, seed=8 + i, mode="partial")
+    dt1 = time.time() - t0
+    out["cfg1"] = {"value": round(4 * 4 / dt1, 4), "unit": "images/s", "sample": f"4 `partial` train steps (num_batches = 4) at LB=UB=2, 256x256, fp32, {dt1:.1f} s after one warm-up step"}
     return out
 
 
-PMC_FILE = "r03_pmc.json"
-PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r03_pmc.json (the shipped arithmetic: --mi-precision f16f8)
+PMC_FILE = "r04_pmc.json"
+PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r04_pmc.json (the shipped arithmetic: --mi-precision f16f8)
     "iic_local_bwd[p3]": "local_bwd_f8_kernel<20, 3", "iic_local_bwd[p1]": "local_bwd_rows_kernel<20, 1, 3",
     "iic_local_joint_fwd[p3]": "joint_fwd_px_kernel<3, 3>", "iic_local_joint_fwd[p1]": "joint_fwd_px_kernel<1, 3>",
 }
@@ -140,7 +150,7 @@ def pmc_fields(tag, flops_per_call, lib_version, args, path=None):
     """traffic (HBM bytes per launch, FETCH_SIZE + WRITE_SIZE), mfma_busy_frac (SQ_VALU_MFMA_BUSY_CYCLES / all SIMD cycles),
     clock_ghz and ceiling_frac = algorithmic flop / flop of the MFMAs the kernel issues (SQ_INSTS_MFMA x flop per instruction): what
     `frac` would read with the matrix pipe 100 % busy at the clock the peak is quoted for -- the operand split issues extra MFMAs per
-    algorithmic product (bf16x3: three; f16f8: one f16 + half a block-scaled fp8 one = the pipe time of two) and tiles pad.  All null unless profiles/r03_pmc.json was taken on this library version, shape and arithmetic."""
+    algorithmic product (bf16x3: three; f16f8: one f16 + half a block-scaled fp8 one = the pipe time of two) and tiles pad.  All null unless profiles/r04_pmc.json was taken on this library version, shape and arithmetic."""
     none = {"traffic": None, "mfma_busy_frac": None, "ceiling_frac": None, "clock_ghz": None, "pmc_source": None}
     try:
         pmc = json.load(open(path or os.path.join(ROOT, "profiles", PMC_FILE)))

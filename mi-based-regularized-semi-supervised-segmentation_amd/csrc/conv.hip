@@ -348,10 +348,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvSrc src, int N,
 //   * consecutive tiles of a block are spatial neighbours (their halos hit the XCD's L2 while still warm) and share the weight slice.
 // Arithmetic, tile shape, LDS layout and epilogues are those of conv3x3_kernel; only the summation order of the statistics differs
 // (per block over its tiles instead of per tile).
-template <typename T, int COT, int TW, int THT, bool POOL, int NW>
+template <typename T, int COT, int TW, int THT, bool POOL, int NW, int DEPTH>
 __global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int N, int H, int W, const T* __restrict__ wpk, int Cout,
                                                            T* __restrict__ out, float* __restrict__ stats, BnFinish fin, int ntiles, int per) {
     static_assert(sizeof(T) == 2, "persistent tiled form: 16-bit storage types");
+    static_assert(DEPTH == 1 || DEPTH == 2, "stages in flight ahead of the one on the matrix cores");
     typedef Mma<T> MM;
     constexpr int kCT = 64 * NW;
     static_assert(THT % NW == 0, "whole rows per wave");
@@ -367,10 +368,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int
     const int tilesC = (W + TW - 1) / TW, tilesR = (H + THT - 1) / THT;
     const int co0 = blockIdx.y * COT;
     const int t_begin = blockIdx.x * per, t_end = min(t_begin + per, ntiles);
+    const int nck = (Cin + CK - 1) / CK;
 
-    uint4 pin[NIS], pwt[NWS];
+    // A STAGE = one 32-channel chunk of one tile (haloed input + weights).  DEPTH stages are in flight in registers ahead of the one
+    // on the matrix cores, across tile boundaries: set A / set B alternate (static register names: the stage loop is unrolled by two).
+    uint4 pinA[NIS], pwtA[NWS], pinB[DEPTH == 2 ? NIS : 1], pwtB[DEPTH == 2 ? NWS : 1];
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    auto fetch = [&](int n, int h0, int w0, int c0) __attribute__((always_inline)) {
+    auto fetch = [&](uint4 (&pin)[NIS], uint4 (&pwt)[NWS], int n, int h0, int w0, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NIS; ++j) {
             const int idx = tid + kCT * j;
@@ -408,118 +412,131 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[t][r] = s2[t][r] = 0.f;
+    f32x4 acc[MTW][NT];
 
-    // tile coordinates are block-uniform: decoded once per tile (scalar unit), never inside the fetch
-    int nn = 0, nh0 = 0, nw0 = 0;
-    if (t_begin < t_end) {
-        nn = t_begin / (tilesC * tilesR); nh0 = ((t_begin / tilesC) % tilesR) * THT; nw0 = (t_begin % tilesC) * TW;
-        fetch(nn, nh0, nw0, 0);
+    // two cursors over the block's stages, both block-uniform (scalar unit): f = the next stage to FETCH, p = the stage to PROCESS
+    struct Cur { int tile, ck, n, h0, w0; };
+    auto decode = [&](Cur& c) __attribute__((always_inline)) {
+        c.n = c.tile / (tilesC * tilesR); c.h0 = ((c.tile / tilesC) % tilesR) * THT; c.w0 = (c.tile % tilesC) * TW;
+    };
+    auto advance = [&](Cur& c) __attribute__((always_inline)) {
+        if (++c.ck == nck) { c.ck = 0; ++c.tile; if (c.tile < t_end) decode(c); }
+    };
+    Cur f{t_begin, 0, 0, 0, 0}, p{t_begin, 0, 0, 0, 0};
+    if (t_begin < t_end) { decode(f); p = f; }
+    if (f.tile < t_end) { fetch(pinA, pwtA, f.n, f.h0, f.w0, 0); advance(f); }
+    if constexpr (DEPTH == 2) {
+        if (f.tile < t_end) { fetch(pinB, pwtB, f.n, f.h0, f.w0, f.ck * CK); advance(f); }
     }
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const int n = nn, h0 = nh0, w0 = nw0;
-        const bool more = tile + 1 < t_end;
-        if (more) { const int t1 = tile + 1; nn = t1 / (tilesC * tilesR); nh0 = ((t1 / tilesC) % tilesR) * THT; nw0 = (t1 % tilesC) * TW; }
-        f32x4 acc[MTW][NT];
+    auto stage = [&](uint4 (&pin)[NIS], uint4 (&pwt)[NWS]) __attribute__((always_inline)) {
+        if (p.ck == 0) {
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int c0 = 0; c0 < Cin; c0 += CK) {
-            __syncthreads();                       // the previous chunk's MFMAs are done with Is / Ws
-#pragma unroll
-            for (int j = 0; j < NIS; ++j) {
-                const int idx = tid + kCT * j;
-                if (idx < IH * IW * (CK / VEC)) *reinterpret_cast<uint4*>(Is + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pin[j];
-            }
-#pragma unroll
-            for (int j = 0; j < NWS; ++j) {
-                const int idx = tid + kCT * j;
-                if (idx < 9 * COT * (CK / VEC)) *reinterpret_cast<uint4*>(Ws + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pwt[j];
-            }
-            __syncthreads();
-            {   // ONE fetch site: the next chunk of this tile, or -- across the tile boundary, in flight under this tile's epilogue --
-                const bool last = c0 + CK >= Cin;                    // chunk 0 of the next tile
-                if (!last || more) fetch(last ? nn : n, last ? nh0 : h0, last ? nw0 : w0, last ? 0 : c0 + CK);
-            }
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
-                typename MM::Frag bf[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bf[t] = MM::load(Wb + (tap * COT + t * 16) * KP, kq);
-#pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    typename MM::Frag af = MM::load(Ib + ((m / MTR + ky) * IW + (m % MTR) * 16 + kx) * KP, kq);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);   // D^T: rows = channels, cols = pixels
-                }
-            }
+                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // ---- epilogue of this tile (conv3x3_kernel's): a lane owns 4 consecutive channels of one pixel
-        if (POOL) {
-            static_assert(!POOL || RW % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
-            const int Hp = H >> 1, Wp = W >> 1;
+        __syncthreads();                       // the previous stage's MFMAs are done with Is / Ws
 #pragma unroll
-            for (int mp = 0; mp < MTW / 2; ++mp) {
-                const int m0 = (2 * (mp / MTR)) * MTR + mp % MTR, m1 = m0 + MTR;
-                const int hp = ((h0 + wv * RW) >> 1) + mp / MTR, wp = ((w0 + (mp % MTR) * 16) >> 1) + (l15 >> 1);
-                const bool mine = !(l15 & 1) && hp < Hp && wp < Wp;
-                T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout;
+        for (int j = 0; j < NIS; ++j) {
+            const int idx = tid + kCT * j;
+            if (idx < IH * IW * (CK / VEC)) *reinterpret_cast<uint4*>(Is + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pin[j];
+        }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int co = co0 + t * 16 + kq * 4;
-                    T pk[4];
+        for (int j = 0; j < NWS; ++j) {
+            const int idx = tid + kCT * j;
+            if (idx < 9 * COT * (CK / VEC)) *reinterpret_cast<uint4*>(Ws + (idx / (CK / VEC)) * KP + (idx % (CK / VEC)) * VEC) = pwt[j];
+        }
+        __syncthreads();
+        if (f.tile < t_end) { fetch(pin, pwt, f.n, f.h0, f.w0, f.ck * CK); advance(f); }      // this register set is free again: DEPTH stages ahead
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[m0][t][r] + acc[m1][t][r];
-                        v += __shfl_xor(v, 1, 64);
-                        pk[r] = from_f32<T>(v);
-                    }
-                    if (!mine) continue;
-                    if (co + 3 < Cout) *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
-                    else {
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            typename MM::Frag bf[NT];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (co + r < Cout) op[co + r] = pk[r];
-                    }
-                }
-            }
-        } else {
+            for (int t = 0; t < NT; ++t) bf[t] = MM::load(Wb + (tap * COT + t * 16) * KP, kq);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
-                const bool ok = h < H && w < W;
-                const size_t px = ((size_t)n * H + h) * W + w;
+                typename MM::Frag af = MM::load(Ib + ((m / MTR + ky) * IW + (m % MTR) * 16 + kx) * KP, kq);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int co = co0 + t * 16 + kq * 4;
-                    T* op = out + px * Cout;
-                    if (fin.out1) op = co < fin.split ? out + px * fin.split : reinterpret_cast<T*>(fin.out1) + px * (Cout - fin.split) - fin.split;
-                    if (ok && co + 3 < Cout) {
+                for (int t = 0; t < NT; ++t) MM::mma_chunk(bf[t], af, acc[m][t]);   // D^T: rows = channels, cols = pixels
+            }
+        }
+        if (p.ck == nck - 1) {
+            // ---- epilogue of this tile (conv3x3_kernel's): a lane owns 4 consecutive channels of one pixel
+            const int n = p.n, h0 = p.h0, w0 = p.w0;
+            if (POOL) {
+                static_assert(!POOL || RW % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
+                const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+                for (int mp = 0; mp < MTW / 2; ++mp) {
+                    const int m0 = (2 * (mp / MTR)) * MTR + mp % MTR, m1 = m0 + MTR;
+                    const int hp = ((h0 + wv * RW) >> 1) + mp / MTR, wp = ((w0 + (mp % MTR) * 16) >> 1) + (l15 >> 1);
+                    const bool mine = !(l15 & 1) && hp < Hp && wp < Wp;
+                    T* op = out + (((size_t)n * Hp + hp) * Wp + wp) * Cout;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int co = co0 + t * 16 + kq * 4;
                         T pk[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = acc[m][t][r];
+                            float v = acc[m0][t][r] + acc[m1][t][r];
+                            v += __shfl_xor(v, 1, 64);
                             pk[r] = from_f32<T>(v);
-                            s1[t][r] += v;
-                            s2[t][r] += v * v;
                         }
-                        *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
-                    } else if (ok) {
+                        if (!mine) continue;
+                        if (co + 3 < Cout) *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                        else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (co + r < Cout) {
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < Cout) op[co + r] = pk[r];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int h = h0 + wv * RW + m / MTR, w = w0 + (m % MTR) * 16 + l15;
+                    const bool ok = h < H && w < W;
+                    const size_t px = ((size_t)n * H + h) * W + w;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int co = co0 + t * 16 + kq * 4;
+                        T* op = out + px * Cout;
+                        if (fin.out1) op = co < fin.split ? out + px * fin.split : reinterpret_cast<T*>(fin.out1) + px * (Cout - fin.split) - fin.split;
+                        if (ok && co + 3 < Cout) {
+                            T pk[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
                                 const float v = acc[m][t][r];
-                                op[co + r] = from_f32<T>(v);
+                                pk[r] = from_f32<T>(v);
                                 s1[t][r] += v;
                                 s2[t][r] += v * v;
                             }
+                            *reinterpret_cast<uint2*>(op + co) = *reinterpret_cast<const uint2*>(pk);
+                        } else if (ok) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < Cout) {
+                                    const float v = acc[m][t][r];
+                                    op[co + r] = from_f32<T>(v);
+                                    s1[t][r] += v;
+                                    s2[t][r] += v * v;
+                                }
+                        }
                     }
                 }
             }
         }
+        advance(p);
+    };
+    while (p.tile < t_end) {
+        stage(pinA, pwtA);
+        if constexpr (DEPTH == 2) {
+            if (p.tile >= t_end) break;
+            stage(pinB, pwtB);
+        }
     }
-    if (!POOL && stats) {          // one partial row per block (a block without tiles writes zeros)
+    if (!POOL && stats) {          // one partial row per block
         __shared__ float sred[NW][2][COT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -1624,9 +1641,16 @@ static void launch_tiled(dim3 grid, hipStream_t st, const ConvSrc& s, int N, int
             const int ntiles = (int)grid.x;
             const PtGrid g = pt_grid(ntiles, (int)grid.y, THH);
             constexpr int NWW = (THH == 16) ? 8 : 4;
-            hipFuncSetAttribute((const void*)conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-            hipLaunchKernelGGL((conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW>), dim3((unsigned)g.blocks, grid.y), dim3(64 * NWW), lb, st, s, N, H, W,
-                               (const TT*)wpk, Cout, (TT*)out, stats, fin, ntiles, g.per);
+            static const int depth = [] { const char* e = getenv("MISEG_CONV_DEPTH"); return e ? atoi(e) : 2; }();
+            if (depth == 2 && !POOL) {      // (the pooled 64-channel form with two stages in flight needs 256 registers: one wave per SIMD)
+                hipFuncSetAttribute((const void*)conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL((conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW, 2>), dim3((unsigned)g.blocks, grid.y), dim3(64 * NWW), lb, st, s, N, H, W,
+                                   (const TT*)wpk, Cout, (TT*)out, stats, fin, ntiles, g.per);
+            } else {
+                hipFuncSetAttribute((const void*)conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL((conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW, 1>), dim3((unsigned)g.blocks, grid.y), dim3(64 * NWW), lb, st, s, N, H, W,
+                                   (const TT*)wpk, Cout, (TT*)out, stats, fin, ntiles, g.per);
+            }
             return;
         }
     }

@@ -150,11 +150,16 @@ class LossScaler:
         self.scale, self.growth_interval, self.max_scale = float(init_scale), int(growth_interval), float(max_scale)
         self.good, self.overflows = 0, 0
 
-    def update(self, nonfinite: float) -> None:
+    def update(self, nonfinite: float, used_scale: Optional[float] = None) -> None:
+        """``nonfinite``: the iteration's count of inf / NaN gradient entries; ``used_scale``: the scale that iteration was staged with.
+        The count arrives one iteration late, so the iteration after an overflow has already been staged with the same scale and
+        overflows too: only an overflow at the CURRENT scale halves it (one overflow event = one halving, as torch.cuda.amp.GradScaler
+        does with its synchronous check); every overflowed iteration is counted and has skipped its update on the device."""
         if nonfinite != 0.0 or nonfinite != nonfinite:
             self.overflows += 1
             self.good = 0
-            self.scale = max(1.0, self.scale * 0.5)
+            if used_scale is None or used_scale <= self.scale:
+                self.scale = max(1.0, self.scale * 0.5)
         else:
             self.good += 1
             if self.good >= self.growth_interval:
@@ -296,6 +301,11 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     # ---- torch.optim.Adam-compatible checkpoints (per-parameter exp_avg / exp_avg_sq / step)
+    def step_skipped(self) -> None:
+        """An iteration reported (one iteration late) that the device skipped its update (gradient overflow in the fp16 mode): take it
+        back out of the step counters, so that the bias corrections count applied updates only, as torch.optim.Adam under a GradScaler."""
+        self._steps = [max(0, t - 1) for t in self._steps]
+
     def state_dict(self) -> dict:
         state: Dict[int, dict] = {}
         groups = []
@@ -312,7 +322,10 @@ class FusedAdam(torch.optim.Optimizer):
                 ids.append(idx)
                 idx += 1
             groups.append({**{k: v for k, v in group.items() if k != "params"}, "params": ids})
-        return {"state": state, "param_groups": groups}
+        out = {"state": state, "param_groups": groups}
+        if self.loss_scaler is not None:       # fp16 storage mode only (the fp32 / bf16 checkpoints keep torch.optim.Adam's exact key set)
+            out["loss_scaler"] = self.loss_scaler.state_dict()
+        return out
 
     def _apply_state(self, sd: dict) -> None:
         idx = 0
@@ -328,6 +341,10 @@ class FusedAdam(torch.optim.Optimizer):
                 idx += 1
 
     def load_state_dict(self, state_dict: dict) -> None:
+        if state_dict.get("loss_scaler") is not None:
+            if self.loss_scaler is None:
+                self.loss_scaler = LossScaler(float(state_dict["loss_scaler"]["scale"]))
+            self.loss_scaler.load_state_dict(state_dict["loss_scaler"])
         for group, saved in zip(self.param_groups, state_dict["param_groups"]):
             for k, v in saved.items():
                 if k != "params":

@@ -38,10 +38,11 @@ def current() -> Optional["StepIO"]:
 
 class Ticket:
     """What ``StepIO.post`` hands back: where the iteration's read-back will land and the event that says it has."""
-    __slots__ = ("io", "slot", "fields", "names", "items", "nvals")
+    __slots__ = ("io", "slot", "fields", "names", "items", "nvals", "scale")
 
     def __init__(self, io, slot, fields, names, items, nvals):
         self.io, self.slot, self.fields, self.names, self.items, self.nvals = io, slot, fields, names, items, nvals
+        self.scale = io.scale          # the loss scale this iteration was staged with (fp16 mode: flat.LossScaler.update)
 
 
 class StepIO:

@@ -528,8 +528,10 @@ class TrainEpocher(_num_class_mixin, _Epocher):
         inter, union = extras[0], extras[1]
         if len(extras) > 2:         # fp16 mode: the gradient's non-finite count -> the loss scale of the iterations still to be enqueued
             scaler = self._optimizer.loss_scaler
-            before = scaler.scale
-            scaler.update(float(extras[2][0]))
+            before, bad = scaler.scale, float(extras[2][0])
+            scaler.update(bad, getattr(ticket, "scale", None))
+            if (bad != 0.0 or bad != bad) and hasattr(self._optimizer, "step_skipped"):
+                self._optimizer.step_skipped()          # the device skipped that update: it does not count towards the bias corrections
             if scaler.scale < before:
                 import warnings
                 warnings.warn(f"fp16 gradient overflow: that optimiser step was skipped, loss scale {before:g} -> {scaler.scale:g}")

@@ -18,7 +18,7 @@ SIMDS, XCDS = 1024, 8
 # flop per MFMA instruction of the shape each kernel family issues (16x16x32 bf16: 2*16*16*32; 32x32x16: 2*32*32*16; 16x16x4 f32: 2*16*16*4)
 MFMA_FLOP = (("local_bwd", 16384), ("joint_fwd", 16384), ("conv3x3_wgrad", 32768), ("conv3x3", 16384), ("head_local_fwd_mfma", 16384),
              ("head_local_bwd_wave", 16384), ("head_local_bwd_fused", 16384))
-FAMILIES = ("local_bwd_rows_kernel", "local_bwd_f8_kernel", "local_bwd_bf16_kernel", "joint_fwd_bf16_kernel", "joint_fwd_px_kernel", "conv3x3_stream_kernel", "conv3x3_kernel",
+FAMILIES = ("local_bwd_rows_kernel", "local_bwd_f8_kernel", "local_bwd_bf16_kernel", "joint_fwd_bf16_kernel", "joint_fwd_px_kernel", "conv3x3_stream_kernel", "conv3x3_kernel", "conv3x3_pt_kernel",
             "conv3x3_wgrad_bf16_kernel", "conv3x3_wgrad_c16_kernel", "head_local_fwd_mfma_kernel", "head_local_bwd_wave_kernel",
             "head_local_bwd_fused_kernel", "bn_relu_bwd", "bn_relu_fwd")
 

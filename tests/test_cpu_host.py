@@ -408,3 +408,41 @@ def test_lazy_evaluate_isolates_non_finite_values_and_keeps_flags_out_of_the_pro
         pend.put("other", la)
     with pytest.raises(RuntimeError, match="loss is nan"):
         pend.fetch()
+
+
+def test_loss_scaler_policy_and_state():
+    """flat.LossScaler: the overflow count of an iteration arrives one iteration late.  An overflow at the current scale halves it; the
+    iteration that had already been staged with the old scale overflows too but must not halve again; `growth_interval` clean
+    iterations double it; state round-trips through state_dict (the optimiser checkpoints it in the fp16 mode)."""
+    from miseg_amd.flat import LossScaler
+    sc = LossScaler(1024.0, growth_interval=3, max_scale=4096.0)
+    sc.update(5.0, used_scale=1024.0)
+    assert sc.scale == 512.0 and sc.overflows == 1
+    sc.update(2.0, used_scale=1024.0)            # staged before the first count arrived: counted, not halved again
+    assert sc.scale == 512.0 and sc.overflows == 2
+    sc.update(float("nan"), used_scale=512.0)
+    assert sc.scale == 256.0 and sc.overflows == 3
+    for _ in range(3):
+        sc.update(0.0, used_scale=256.0)
+    assert sc.scale == 512.0 and sc.good == 0
+    sd = sc.state_dict()
+    other = LossScaler(1.0)
+    other.load_state_dict(sd)
+    assert (other.scale, other.good, other.overflows) == (sc.scale, sc.good, sc.overflows)
+    sc.update(1.0)                               # no scale given (stand-alone use): halves
+    assert sc.scale == 256.0
+
+
+def test_bigstep_oracle_cache_is_current():
+    """tests/golden/bigstep_oracle.npz caches four oracle steps that cost minutes of CPU (tests/golden/bigstep.py); the GPU tests use it
+    only while the fingerprint of oracle/ + synth.py + bigstep.py stored in it matches.  A mismatch here means: regenerate it
+    (`python tests/golden/bigstep.py`), or the GPU suite silently spends those minutes again."""
+    import bigstep
+    import numpy as np
+    assert os.path.exists(bigstep.CACHE), "tests/golden/bigstep_oracle.npz is missing: python tests/golden/bigstep.py"
+    z = np.load(bigstep.CACHE, allow_pickle=False)
+    assert str(z["fingerprint"]) == bigstep.fingerprint(), "oracle/ or synth.py changed: regenerate with python tests/golden/bigstep.py"
+    for key in ("cfg2/fp32", "cfg2/bf16", "cfg4/fp32", "cfg4/bf16"):
+        names = [str(n) for n in z[f"{key}/scalar_names"]]
+        assert {"sup_loss", "uda", "mi", "reg_loss", "mi/Up_conv2"} <= set(names), (key, names)
+        assert len(z[f"{key}/grad_names"]) >= 8

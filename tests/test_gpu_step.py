@@ -441,7 +441,10 @@ def test_fp16_dynamic_loss_scale_under_the_tape():
             ep._flush_records()
         assert tp.replays == 4
         assert torch.equal(opt.flat.flat_param.detach(), before)        # three skipped updates
-        assert scaler.scale == 2.0 ** 37 and scaler.overflows == 3
+        # three overflowed (skipped) iterations; the scale halves once per overflow AT THE CURRENT SCALE: the iteration staged before the
+        # first count arrived overflowed at the old scale and does not halve again (flat.LossScaler.update)
+        assert scaler.scale == 2.0 ** 38 and scaler.overflows == 3
+        assert opt._steps[0] == 4                                       # skipped updates do not count towards the bias corrections
         scaler.scale = 16384.0
         for _ in range(2):
             drv.step()
@@ -618,26 +621,13 @@ _CFG2_ORACLE = {}
 
 
 def _cfg2_oracle():
-    """ONE oracle step at BASELINE configs[1]'s shape (LB = UB = 16, 256 x 256, default taps / heads / paddings): ~35 s of CPU, shared
-    by the parametrisations below."""
+    """ONE oracle step at BASELINE configs[1]'s shape (LB = UB = 16, 256 x 256, default taps / heads / paddings): ~35 s of CPU -- taken
+    from tests/golden/bigstep_oracle.npz while the fingerprint of oracle/ + synth.py stored there still matches (tests/golden/bigstep.py),
+    recomputed otherwise; shared by the parametrisations below."""
     if not _CFG2_ORACLE:
-        from oracle import step as OS
-        H, LB, UB = 256, 16, 16
-        heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=41), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=42),
-                 "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=43)}
-        limg, ltgt = T(synth.uniform("cfg2step/lab", (LB, 1, H, H))), T(synth.integers("cfg2step/tgt", (LB, 1, H, H), 4))
-        uimg = T(synth.uniform("cfg2step/unl", (UB, 1, H, H)))
-        random.seed(2468)
-        seed = random.randint(0, int(1e7))               # the flip seed the epocher draws for iteration 1 (ref epocher.py:146)
-        state = OS.StepState(OU.init_state(1, 4, seed=40), heads, lr=1e-3, weight_decay=1e-5)
-        threads = torch.get_num_threads()
-        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
-        try:
-            sc, grads = OS.train_step(state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0,
-                                      iic_weight=0.1, do_update=False)
-        finally:
-            torch.set_num_threads(threads)
-        _CFG2_ORACLE.update(heads=heads, limg=limg, ltgt=ltgt, uimg=uimg, sc=sc, grads=grads, seed=seed)
+        import bigstep
+        sc, grads = bigstep.result("cfg2", False)
+        _CFG2_ORACLE.update(bigstep.cfg2_inputs(), sc=sc, grads=grads)
     return _CFG2_ORACLE
 
 
@@ -647,15 +637,8 @@ def _cfg2_oracle_bf16():
     differs from any bf16 evaluation of this random-init net by 10-25 % in the consistency term alone."""
     o = _cfg2_oracle()
     if "sc_bf16" not in o:
-        from oracle import step as OS
-        state = OS.StepState(OU.init_state(1, 4, seed=40), o["heads"], lr=1e-3, weight_decay=1e-5)
-        threads = torch.get_num_threads()
-        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
-        try:
-            sc, grads = OS.train_step(state, o["limg"], o["ltgt"], o["uimg"], o["seed"], mode="udaiic", feature_importance=[0.5, 0.25, 0.25],
-                                      cons_weight=5.0, iic_weight=0.1, do_update=False, unet_fn=OU.unet_forward_bf16_autograd)
-        finally:
-            torch.set_num_threads(threads)
+        import bigstep
+        sc, grads = bigstep.result("cfg2", True)
         o.update(sc_bf16=sc, grads_bf16=grads)
     return o
 
@@ -777,7 +760,8 @@ def test_count_nonfinite_guards_the_fused_adam():
 def test_fp16_overflow_skips_the_step_and_halves_the_loss_scale(monkeypatch):
     """BASELINE configs[4]'s arithmetic (IEEE-half storage) with an absurd initial loss scale (2^40: every activation gradient leaves
     half's range): the overflow count guards the fused Adam on the device -- no weight, no moment moves -- and the scale follows one
-    iteration late (flat.LossScaler): three iterations -> three overflows seen, scale 2^37.  With the default scale the same three
+    iteration late (flat.LossScaler): three iterations -> three overflows seen, two of them at the then-current scale -> scale 2^38
+    (the iteration staged before the first count arrived does not halve it again).  With the default scale the same three
     iterations are clean and move the weights."""
     import warnings
     from semi_seg.epocher import UDAIICEpocher
@@ -803,7 +787,7 @@ def test_fp16_overflow_skips_the_step_and_halves_the_loss_scale(monkeypatch):
         assert sc is not None and sc.overflows == expect_overflows, (sc.overflows, sc.scale)
         moved = any(not torch.equal(before[k], v) for k, v in model.state_dict().items() if k.endswith("weight"))
         if expect_overflows:
-            assert sc.scale == init / 8 and not moved
+            assert sc.scale == init / 4 and not moved and opt._steps[0] == 0
             assert any("overflow" in str(w.message) for w in caught)
             assert all(float(m.abs().max()) == 0 for m in opt._m)            # the moments did not move either
         else:
@@ -830,11 +814,10 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
     from semi_seg.epocher import UDAIICEpocher
     from itertools import chain
     from miseg_amd import ops as _ops, unet_ops
+    import bigstep
     H, LB, UB, NC, PATCH = 256, 1, 1, 8, 64
-    heads = {"Conv5": OH.init_cluster_head(256, 20, 5, "linear", seed=51), "Up_conv3": OH.init_local_cluster_head(32, 20, 5, "linear", seed=52),
-             "Up_conv2": OH.init_local_cluster_head(16, 20, 5, "linear", seed=53)}
-    limg, ltgt = T(synth.uniform("cfg4step/lab", (LB, 1, H, H))), T(synth.integers("cfg4step/tgt", (LB, 1, H, H), NC))
-    uimg = T(synth.uniform("cfg4step/unl", (UB, 1, H, H)))
+    inp = bigstep.cfg4_inputs()
+    heads, limg, ltgt, uimg = inp["heads"], inp["limg"], inp["ltgt"], inp["uimg"]
     model = UNet(1, NC, compute_dtype=dtype)
     model.load_state_dict(OU.init_state(1, NC, seed=50))
     pw = ProjectorWrapper()
@@ -865,34 +848,12 @@ def test_cfg4_step_matches_the_oracle(monkeypatch, dtype, mi_precision):
                             feature_importance=[0.5, 0.25, 0.25], cons_weight=5.0, iic_weight=0.1).run()
     finally:
         _ops.set_mi_precision("fp32")
-    if not _CFG4_ORACLE:        # one oracle step (~1 min of CPU) shared by the two parametrisations
-        random.seed(1357)
-        seed = random.randint(0, int(1e7))
-        state = OS.StepState(OU.init_state(1, NC, seed=50), heads, lr=1e-3, weight_decay=1e-5)
-        threads = torch.get_num_threads()
-        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
-        try:
-            _CFG4_ORACLE["sc"], _CFG4_ORACLE["grads"] = OS.train_step(
-                state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], paddings=[1, 3], patch_sizes=[PATCH, PATCH],
-                cons_weight=5.0, iic_weight=0.1, num_classes=NC, do_update=False)
-        finally:
-            torch.set_num_threads(threads)
+    # the oracle steps (~1 min of CPU each, fp32 and bf16-emulated): cached in tests/golden/bigstep_oracle.npz (bigstep.py), recomputed
+    # if oracle/ or the input generator changed since
     exact = dtype == "float32"
-    if not exact and "sc_bf16" not in _CFG4_ORACLE:     # bf16 storage: the oracle with the same rounding points (another CPU minute)
-        random.seed(1357)
-        seed = random.randint(0, int(1e7))
-        state = OS.StepState(OU.init_state(1, NC, seed=50), heads, lr=1e-3, weight_decay=1e-5)
-        threads = torch.get_num_threads()
-        torch.set_num_threads(max(threads, min(16, os.cpu_count() or 1)))
-        try:
-            _CFG4_ORACLE["sc_bf16"], _CFG4_ORACLE["grads_bf16"] = OS.train_step(
-                state, limg, ltgt, uimg, seed, mode="udaiic", feature_importance=[0.5, 0.25, 0.25], paddings=[1, 3], patch_sizes=[PATCH, PATCH],
-                cons_weight=5.0, iic_weight=0.1, num_classes=NC, do_update=False, unet_fn=OU.unet_forward_bf16_autograd)
-        finally:
-            torch.set_num_threads(threads)
-    sc, grads = (_CFG4_ORACLE["sc"], _CFG4_ORACLE["grads"])
-    if not exact:
-        sc = _CFG4_ORACLE["sc_bf16"]
+    sc, grads = bigstep.result("cfg4", False)
+    if not exact:        # bf16 storage: the oracle with the same rounding points
+        sc = bigstep.result("cfg4", True)[0]
     _dump(f"cfg4_scalars_{dtype}_{mi_precision}", {k: (abs(res[k]["mean"] - sc[k]) / (abs(sc[k]) + 1e-30), res[k]["mean"], sc[k])
                                                     for k in ("sup_loss", "uda", "mi", "reg_loss")})
     np.testing.assert_allclose(res["sup_loss"]["mean"], sc["sup_loss"], rtol=2e-5 if exact else 5e-3)
