@@ -1641,7 +1641,9 @@ static void launch_tiled(dim3 grid, hipStream_t st, const ConvSrc& s, int N, int
             const int ntiles = (int)grid.x;
             const PtGrid g = pt_grid(ntiles, (int)grid.y, THH);
             constexpr int NWW = (THH == 16) ? 8 : 4;
-            static const int depth = [] { const char* e = getenv("MISEG_CONV_DEPTH"); return e ? atoi(e) : 2; }();
+            // stages in flight ahead of the matrix cores: ONE.  Two (201 instead of 155 registers in the 32-channel-slice form) measured
+            // 6.72 / 6.73 against 6.66 / 6.63 ms per step, same box, two alternations (gpurun_out/ab_depth_*.json); MISEG_CONV_DEPTH=2 selects it
+            static const int depth = [] { const char* e = getenv("MISEG_CONV_DEPTH"); return e ? atoi(e) : 1; }();
             if (depth == 2 && !POOL) {      // (the pooled 64-channel form with two stages in flight needs 256 registers: one wave per SIMD)
                 hipFuncSetAttribute((const void*)conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 hipLaunchKernelGGL((conv3x3_pt_kernel<TT, COT, TWW, THH, POOL, NWW, 2>), dim3((unsigned)g.blocks, grid.y), dim3(64 * NWW), lb, st, s, N, H, W,
