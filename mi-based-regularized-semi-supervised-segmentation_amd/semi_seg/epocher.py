@@ -470,6 +470,8 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             self._pending.put("sup_loss", sup_loss)
             self._pending.put("reg_loss", reg_loss)
         io = stepio.CURRENT
+        with torch.no_grad():      # (before the optimiser launch, which first waits for the weight-gradient stream: these run under that tail)
+            _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False, to_host=True)
         if hasattr(self._optimizer, "apply"):
             # The iteration's report (meter values + the simplex / NaN flags) is computed here, in one launch, and its flags guard
             # the update on the device: the host raises a failed check one iteration late, but it has not moved the weights
@@ -477,8 +479,6 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             self._optimizer.apply(guard=self._pending.precompute() if _GUARD_STEP else None, io=io)
         else:
             self._optimizer.step()
-        with torch.no_grad():
-            _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False, to_host=True)
         self._overflow = getattr(self._optimizer, "last_nonfinite", None)     # device float[1] in the fp16 mode, else None
         return inter, union
 
