@@ -160,8 +160,11 @@ class StepTape:
         key = self._key(io, li, lt, ui, len(flip_masks))
         if self.handle and key == self.key:
             return self._replay(io, li, lt, ui, flip_masks)
-        if self.handle:                     # another batch shape (a short last batch): eager, the tape stays for the usual one
-            return ep._run_step(io, li, lt, ui, flip_masks)
+        if self.handle:
+            if key[-3:] != self.key[-3:]:   # the persistent state moved or the trainer changed: the recorded pointers are void
+                self.release()
+                self.seen = 0
+            return ep._run_step(io, li, lt, ui, flip_masks)      # (another batch shape, e.g. a short last batch: eager, the tape stays)
         if self.seen < self.warmup or not (li.is_contiguous() and lt.is_contiguous() and ui.is_contiguous()):
             self.seen += 1
             return ep._run_step(io, li, lt, ui, flip_masks)

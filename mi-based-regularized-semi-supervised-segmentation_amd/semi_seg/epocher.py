@@ -352,9 +352,15 @@ class TrainEpocher(_num_class_mixin, _Epocher):
     def _tape_signature(self):
         """What, besides shapes, decides the recorded launch list: the trainer kind and its loss coefficients (they are the constant
         gradients that seed backward)."""
+        # ... and where the persistent state lives: a rebuilt flat buffer (FlatBuffers.build after the parameters moved) or moved
+        # BatchNorm buffers would leave the recorded pointers dangling -- a changed address re-records instead
+        opt = self._optimizer
+        where = tuple((fb.flat_param.data_ptr(), fb.flat_grad.data_ptr()) for fb in getattr(opt, "_flats", []) if fb.flat_param is not None)
+        where += tuple(t.data_ptr() for t in getattr(opt, "_m", []) if t is not None)
+        buf = next(iter(self._model.buffers()), None)
         return (type(self).__name__, float(self._reg_weight), getattr(self, "_cons_weight", None), getattr(self, "_iic_weight", None),
                 tuple(self._feature_importance), tuple(self._feature_position), type(self._sup_criterion).__name__,
-                type(getattr(self, "_reg_criterion", None)).__name__)
+                type(getattr(self, "_reg_criterion", None)).__name__, where, None if buf is None else buf.data_ptr(), id(self._model))
 
     def _loss_scale(self) -> float:
         """Current loss scale: 1 unless the activations are IEEE half (BASELINE configs[4]); dynamic from its initial value."""
