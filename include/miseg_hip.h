@@ -158,6 +158,20 @@ int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs, int64_t S,
 int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
                               int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
                               float* gprob, int accumulate, int precision, void* ws, int64_t ws_bytes);
+/* Local-MI operand planes (K = 20, pad = 3: the f16 + fp8 backward).  The backward multiplies every probability as f16 hi + 8-bit cross
+ * terms; with the three images of a map kept in memory PIXEL-major -- p16 [map][H][W][20] f16, p8l / p8h [map][H][W][24] e4m3 of
+ * 2^20 (v - hi) and 2^8 v -- a source row of the kernel is a plain memory -> LDS copy (no registers, no conversions, issued a phase
+ * ahead) instead of 40 loads and ~150 vector instructions per wave and row.  map = s * 2 UB + m, the order of
+ * probs[S][2 UB][K][H][W] (ref contrastyou/losses/iic_loss.py:120-149 differentiated; the operands are the head's outputs,
+ * contrastyou/trainer/_utils.py:149-154).  One buffer of miseg_iic_local_planes_bytes() bytes (0: shape not supported), written by
+ * miseg_iic_local_make_planes or by the joint forward as a by-product.  miseg_iic_local_bwd_heads_planes = miseg_iic_local_bwd_heads
+ * at precision 3, bit for bit, reading the planes in place of probs. */
+int64_t miseg_iic_local_planes_bytes(int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad);
+int miseg_iic_local_make_planes(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad,
+                                void* planes, int64_t planes_bytes);
+int miseg_iic_local_bwd_heads_planes(void* stream, const void* planes, int64_t planes_bytes, int64_t S, int64_t UB, int64_t K, int64_t H,
+                                     int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
+                                     float* gprob, int accumulate, void* ws, int64_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Global IIC mutual information, S sub-heads in one launch
@@ -216,6 +230,15 @@ int miseg_head_local_bwd_rows(void* stream, int dt, const void* feat, int64_t B,
                               const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S,
                               int64_t K, float T, const float* prob, const float* gprob, void* gfeat_rows, int64_t row0,
                               float* gw, float* gb, void* ws, int64_t ws_bytes);
+/* miseg_head_local_bwd_rows WITHOUT the saved probabilities: the kernel computes them again from feat, w and b by the forward
+ * kernel's own operations (bit-equal p), so the backward reads gprob only -- half the bytes of this HBM-bound kernel.  The autograd
+ * node of LocalClusterHead (ref contrastyou/trainer/_utils.py:137-168) keeps its inputs either way.  Shapes of
+ * miseg_head_local_bwd_recompute_supported only (16-bit features, C = 16, S = 5, K = 20: the shipped top tap). */
+int64_t miseg_head_local_bwd_recompute_supported(int dt, int64_t C, int64_t S, int64_t K);
+int miseg_head_local_bwd_recompute(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                   const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* b, int64_t S,
+                                   int64_t K, float T, const float* gprob, void* gfeat_rows, int64_t row0, float* gw, float* gb,
+                                   void* ws, int64_t ws_bytes);
 /* the same, ADDING to gfeat_inout in place of storing (rows of src only; one rounding of the sum): for a tapped feature whose other
  * consumer -- DeConv_1x1 at the last decoder block, unet.py:84,129 -- has already written its input gradient there, so that autograd
  * has nothing left to add (a 300 MB elementwise pass on the step's critical path). */

@@ -599,33 +599,56 @@ __global__ __launch_bounds__(256, (CTM == 1 ? 3 : 2)) void head_local_bwd_fused_
 }
 
 #ifndef MISEG_HB_ABL
-#define MISEG_HB_ABL 0   // timing ablations of head_local_bwd_wave_kernel (scratch builds only): 1 no gw/gb, 2 no gfeat, 3 no MFMA phase, 4 no [k][px] dz writes, 5 = 3 + 4
+#define MISEG_HB_ABL 0   // timing ablations of head_local_bwd_wave_kernel (scratch builds only): 1 no gw/gb, 2 no gfeat, 3 no MFMA phase
 #endif
 // Wave-local backward of the local head for the shipped 16-channel tap (bf16 features, K = 20, S <= 5).  The fused kernel above
 // works a 64-pixel chunk per BLOCK through three phases with workgroup barriers between them; here every WAVE owns its chunks
 // outright and nothing but its own LDS slice is shared, so there is no barrier in the loop (a wave's LDS traffic is in order):
 //   per sub-head: p, g of the lane's pixel (coalesced along pixels) -> dz = p (g - <g,p>) / T in registers -> hi + lo bf16 planes,
-//                 written twice to the wave's LDS: [px][k] rows (operand of gfeat) and [k][px] rows (operand of gw, gb);
+//                 written to the wave's LDS as [px][k] rows: read straight as the operand of gfeat, through the transposing LDS read
+//                 (ds_read_b64_tr_b16) as the [k][px] operand of gw, gb;
 //   gfeat^T[c][px] += W^T[c][k] dz^T[k][px]   3 x mfma_16x16x32_bf16 per 16-pixel tile (W_lo dz_hi + W_hi dz_lo + W_hi dz_hi)
 //   gw[k][c]       += dz^T[k][px] f[px][c]    2 per (32-pixel k-chunk, class tile): dz_lo f + dz_hi f (features are exact bf16)
 //   gb[k]          += dz^T[k][px] 1           the same A fragments against a constant all-ones B fragment
 // gw / gb stay in accumulators over all the wave's chunks; one deterministic partial per block at the end (same workspace and
 // final reduction as the fused kernel).  Precision is the fused BF variant's: hi + lo = 2^-16 relative per term.
-template <int C>
+// RECOMP: the probabilities are not read back but computed again from the features, the way the forward kernel computes them
+// (W in three bf16 planes x features on the MFMA, bias, exp2 softmax: the same operations in the same order, so p is the
+// forward's p bit for bit); `prob` is unused and the kernel reads S*K*4 instead of 2*S*K*4 bytes per pixel.  The logits cross from the
+// D layout (4 classes x 1 pixel per lane) to one pixel per lane through the [k][px] dz rows' LDS, which are free at that point.
+template <int C, bool RECOMP>
 __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16* __restrict__ feat, int H, int W,
                                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ flips,
-                                                                     int M, const float* __restrict__ w, int S, float invT,
-                                                                     const float* __restrict__ prob, const float* __restrict__ gprob,
+                                                                     int M, const float* __restrict__ w, const float* __restrict__ bias, int S,
+                                                                     float invT, const float* __restrict__ prob, const float* __restrict__ gprob,
                                                                      bf16* __restrict__ gfeat, float* __restrict__ partials, int accumulate) {
-    constexpr int K = 20, SM = 5, CT = C / 16, AR = 24, BR = 72;
-    constexpr int WAVE_LDS = (2 * 64 * AR + 2 * K * BR + C * BR) * 2;   // bytes per wave
+    constexpr int K = 20, SM = 5, CT = C / 16, AR = 24, BR = 72, ZS = 68, CQ = C / 4;
+    constexpr int ZT = RECOMP ? K * ZS * 2 : 0;                          // u16 units of the logits' transpose buffer
+    constexpr int WAVE_LDS = (2 * 64 * AR + ZT + C * BR) * 2;            // bytes per wave
+    static_assert(!RECOMP || C == 16, "the recomputing form is the 16-channel tap's");
+    typedef typename HeadFrag<C>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char hb[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     unsigned short* dzA = reinterpret_cast<unsigned short*>(hb + (size_t)wv * WAVE_LDS);   // [2][64][AR]  hi | lo, row = pixel
-    unsigned short* dzB = dzA + 2 * 64 * AR;                                               // [2][K][BR]   hi | lo, row = class
-    unsigned short* fT = dzB + 2 * K * BR;                                                 // [C][BR]      features, row = channel
+    float* ztw = reinterpret_cast<float*>(dzA + 2 * 64 * AR);                              // RECOMP: [K][ZS] logits of the chunk
+    unsigned short* fT = dzA + 2 * 64 * AR + ZT;                                           // [C][BR]      features, row = channel
     unsigned short* wT = reinterpret_cast<unsigned short*>(hb + (size_t)4 * WAVE_LDS);     // [S][2][C][32] W^T hi | lo, classes >= K zero
+    bf16* wp = reinterpret_cast<bf16*>(wT + (size_t)SM * 2 * C * 32);                       // RECOMP: [S][3][K][C] W in three planes
+    float* bs = reinterpret_cast<float*>(wp + (size_t)SM * 3 * K * C);                      // RECOMP: [S][K] bias
     const int HW = H * W, R = S * K;
+    if constexpr (RECOMP) {
+        for (int i = tid; i < S * K * C; i += 256) {      // the forward kernel's split, value for value
+            const float v = w[i];
+            const bf16 h1 = __float2bfloat16(v);
+            const float r1 = v - __bfloat162float(h1);
+            const bf16 h2 = __float2bfloat16(r1);
+            const bf16 h3 = __float2bfloat16(r1 - __bfloat162float(h2));
+            const int s = i / (K * C), rem = i - s * K * C;
+            bf16* d = wp + (size_t)(s * 3) * K * C + rem;
+            d[0] = h1, d[(size_t)K * C] = h2, d[(size_t)2 * K * C] = h3;
+        }
+        for (int i = tid; i < S * K; i += 256) bs[i] = bias[i];
+    }
     for (int i = lane; i < 2 * 64 * AR / 2; i += 64) reinterpret_cast<unsigned*>(dzA)[i] = 0u;   // the pad columns 20..23 stay zero
     for (int i = tid; i < S * 2 * C * 32; i += 256) {
         const int k = i & 31, c = (i >> 5) % C, pl = (i / (32 * C)) & 1, s = i / (64 * C);
@@ -644,9 +667,9 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) agw[s][cl][ct] = zero4;
         }
-    bf16x8h_t ones, zfrag;
+    bf16x8h_t ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f, zfrag[e] = (__bf16)0.0f;
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const int cps = (HW + 63) / 64, total = M * cps, nw = gridDim.x * 4;
     // p, g of the NEXT (chunk, sub-head) are fetched while the current one is worked on: P/G[s & 1] is sub-head s's buffer
     // (S = 5 is odd, so the buffer a chunk ends on is copied down once per chunk)
@@ -655,14 +678,17 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
         const int g0 = min(blockIdx.x * 4 + wv, total - 1), m0 = g0 / cps, pc0 = min((g0 - m0 * cps) * 64 + lane, HW - 1);
         const size_t o = ((size_t)m0 * K) * HW + pc0;
 #pragma unroll
-        for (int k = 0; k < K; ++k) P[0][k] = prob[o + (size_t)k * HW], G[0][k] = gprob[o + (size_t)k * HW];
+        for (int k = 0; k < K; ++k) {
+            if constexpr (!RECOMP) P[0][k] = prob[o + (size_t)k * HW];
+            G[0][k] = gprob[o + (size_t)k * HW];
+        }
     }
     for (int g = blockIdx.x * 4 + wv; g < total; g += nw) {
         const int m = g / cps, px0 = (g - m * cps) * 64;
         const int gn = min(g + nw, total - 1), mn = gn / cps, pcn = min((gn - mn * cps) * 64 + lane, HW - 1);
         const int f = flips ? flips[m] : 0;
         const int px = px0 + lane, pc = min(px, HW - 1);
-        const bool live = px < HW;
+        const float invT_l = px < HW ? invT : 0.f;      // pixels past the end of the sample: dz = 0
         const size_t sbase = (size_t)src[m] * HW;
         {
             const int h = pc / W, wq = pc - h * W;
@@ -672,6 +698,14 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                 const s16x8 v = *reinterpret_cast<const s16x8*>(fp + c0);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) fT[(c0 + e) * BR + lane] = (unsigned short)v[e];
+            }
+        }
+        frag_t fb[4];      // RECOMP: the features as MFMA B operands, pixel t*16 + l15, channels 4q..4q+3
+        if constexpr (RECOMP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pt = min(px0 + t * 16 + l15, HW - 1), h = pt / W, wq = pt - h * W;
+                fb[t] = *reinterpret_cast<const frag_t*>(feat + (sbase + (size_t)flip_h(h, H, f) * W + flip_w(wq, W, f)) * C + q * CQ);
             }
         }
         f32x4 agf[4][CT];
@@ -685,9 +719,58 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                 {
                     const size_t o = s + 1 < SM ? (((size_t)(s + 1) * M + m) * K) * HW + pc : ((size_t)mn * K) * HW + pcn;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) P[(s + 1) & 1][k] = prob[o + (size_t)k * HW], G[(s + 1) & 1][k] = gprob[o + (size_t)k * HW];
+                    for (int k = 0; k < K; ++k) {
+                        if constexpr (!RECOMP) P[(s + 1) & 1][k] = prob[o + (size_t)k * HW];
+                        G[(s + 1) & 1][k] = gprob[o + (size_t)k * HW];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RECOMP) {
+                    frag_t wa[2][3];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const int cls = min(ct * 16 + l15, K - 1);      // class rows >= K: a copy of row K-1; their D rows are never read
+                            wa[ct][pl] = *reinterpret_cast<const frag_t*>(wp + ((size_t)(s * 3 + pl) * K + cls) * C + q * CQ);
+                        }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        f32x4 a0 = zero4, a1 = zero4;
+#pragma unroll
+                        for (int pl = 2; pl >= 0; --pl) {   // smallest plane first, as in the forward
+                            a0 = HeadFrag<C>::mma(wa[0][pl], fb[t], a0);
+                            a1 = HeadFrag<C>::mma(wa[1][pl], fb[t], a1);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ztw[(4 * q + r) * ZS + t * 16 + l15] = a0[r];
+                        if (q == 0)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ztw[(16 + r) * ZS + t * 16 + l15] = a1[r];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    float* z = P[s & 1];
+#pragma unroll
+                    for (int k4 = 0; k4 < K; k4 += 4) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bs + s * K + k4);      // one address for the wave: a broadcast
+                        z[k4] = ztw[k4 * ZS + lane] + bv.x, z[k4 + 1] = ztw[(k4 + 1) * ZS + lane] + bv.y;
+                        z[k4 + 2] = ztw[(k4 + 2) * ZS + lane] + bv.z, z[k4 + 3] = ztw[(k4 + 3) * ZS + lane] + bv.w;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    float mx = -3.4e38f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) mx = fmaxf(mx, z[k]);
+                    const float sc2 = invT * 1.4426950408889634f, off2 = -mx * sc2;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        z[k] = __builtin_amdgcn_exp2f(fmaf(z[k], sc2, off2));
+                        sum += z[k];
+                    }
+                    const float inv = 1.0f / sum;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) z[k] *= inv;
+                }
                 const float* p = P[s & 1];
                 const float* gg = G[s & 1];
                 float dot = 0.f;
@@ -699,13 +782,9 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                     unsigned short h2[2], l2[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const float dz = live ? p[k + e] * (gg[k + e] - dot) * invT : 0.f;
+                        const float dz = p[k + e] * (gg[k + e] - dot) * invT_l;
                         h2[e] = f32_to_bf16_bits(dz);
                         l2[e] = f32_to_bf16_bits(dz - bf16_bits_to_f32(h2[e]));
-#if MISEG_HB_ABL != 4 && MISEG_HB_ABL != 5
-                        dzB[(k + e) * BR + lane] = h2[e];
-                        dzB[(K + k + e) * BR + lane] = l2[e];
-#endif
                     }
                     hw[k / 2] = (unsigned)h2[0] | ((unsigned)h2[1] << 16);
                     lw[k / 2] = (unsigned)l2[0] | ((unsigned)l2[1] << 16);
@@ -720,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                 }
                 __builtin_amdgcn_wave_barrier();
                 // gfeat^T tiles: A = W^T [c][k], B = dz^T [k][px]
-#if MISEG_HB_ABL != 2 && MISEG_HB_ABL != 3 && MISEG_HB_ABL != 5
+#if MISEG_HB_ABL != 2 && MISEG_HB_ABL != 3
                 bf16x8h_t wh[CT], wl[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -729,9 +808,9 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    bf16x8h_t bh = *reinterpret_cast<const bf16x8h_t*>(dzA + (t * 16 + l15) * AR + 8 * min(q, 2));
-                    bf16x8h_t bl = *reinterpret_cast<const bf16x8h_t*>(dzA + (64 + t * 16 + l15) * AR + 8 * min(q, 2));
-                    if (q == 3) bh = zfrag, bl = zfrag;   // classes 24..31: no such columns in the row
+                    // classes 24..31 (q == 3): no such columns in the row -- any finite values do, W^T is zero there
+                    const bf16x8h_t bh = *reinterpret_cast<const bf16x8h_t*>(dzA + (t * 16 + l15) * AR + 8 * min(q, 2));
+                    const bf16x8h_t bl = *reinterpret_cast<const bf16x8h_t*>(dzA + (64 + t * 16 + l15) * AR + 8 * min(q, 2));
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         agf[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ct], bh, agf[t][ct], 0, 0, 0);
@@ -740,16 +819,29 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
                     }
                 }
 #endif
-#if MISEG_HB_ABL != 1 && MISEG_HB_ABL != 3 && MISEG_HB_ABL != 5
+#if MISEG_HB_ABL != 1 && MISEG_HB_ABL != 3
                 // gw, gb: A = dz^T [k][px], B = f [px][c] (or ones)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
                     for (int cl = 0; cl < 2; ++cl) {
-                        const int k = cl * 16 + l15, kk = min(k, K - 1);
-                        bf16x8h_t ah = *reinterpret_cast<const bf16x8h_t*>(dzB + kk * BR + kc * 32 + 8 * q);
-                        bf16x8h_t al = *reinterpret_cast<const bf16x8h_t*>(dzB + (K + kk) * BR + kc * 32 + 8 * q);
-                        if (k >= K) ah = zfrag, al = zfrag;
+                        // class l15 of tile cl, pixels kc*32 + 8q .. +7: out of the [px][k] rows by the transposing read (lane 4qq+pq of a
+                        // 16-lane group supplies 4 classes of pixel qq and receives its own class's 4 pixels).  Tile 1 reads columns
+                        // 16..31 of 24-column rows: classes 24..31 are the next row's first values -- their D rows are never stored.
+                        const unsigned short* a0 = dzA + (kc * 32 + 8 * q + (l15 >> 2)) * AR + cl * 16 + 4 * (l15 & 3);
+                        bf16x8h_t ah, al;
+                        {
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(HLDS_S16X4(a0));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(HLDS_S16X4(a0 + 4 * AR));
+                            const s16x8 fv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            ah = __builtin_bit_cast(bf16x8h_t, fv);
+                        }
+                        {
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(HLDS_S16X4(a0 + 64 * AR));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(HLDS_S16X4(a0 + 64 * AR + 4 * AR));
+                            const s16x8 fv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            al = __builtin_bit_cast(bf16x8h_t, fv);
+                        }
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) {
                             const bf16x8h_t fb = *reinterpret_cast<const bf16x8h_t*>(fT + (ct * 16 + l15) * BR + kc * 32 + 8 * q);
@@ -788,7 +880,10 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < K; ++k) P[0][k] = P[SM & 1][k], G[0][k] = G[SM & 1][k];
+        for (int k = 0; k < K; ++k) {
+            if constexpr (!RECOMP) P[0][k] = P[SM & 1][k];
+            G[0][k] = G[SM & 1][k];
+        }
     }
     // one partial per block: the four waves' accumulators through LDS, summed in wave order
     __syncthreads();
@@ -888,8 +983,8 @@ extern "C" int64_t miseg_head_local_bwd_acc_supported(int dt, int64_t C, int64_t
 }
 
 static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
-                               const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K, float T, const float* prob,
-                               const float* gprob, void* gfeat, float* gw, float* gb, void* ws, int64_t ws_bytes, int accumulate);
+                               const int32_t* flips, int64_t M, const float* w, const float* bias, int64_t S, int64_t K, float T,
+                               const float* prob, const float* gprob, void* gfeat, float* gw, float* gb, void* ws, int64_t ws_bytes, int accumulate);
 
 extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                     const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
@@ -897,7 +992,7 @@ extern "C" int miseg_head_local_bwd(void* stream, int dt, const void* feat, int6
                                     int64_t ws_bytes) {
     MISEG_TAPE(miseg_head_local_bwd, stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes);
-    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes, 0);
+    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, nullptr, S, K, T, prob, gprob, gfeat, gw, gb, ws, ws_bytes, 0);
 }
 
 // gfeat_rows holds rows [row0, row0 + rows) of the batch only (src[] must lie inside): see miseg_hip.h
@@ -912,6 +1007,23 @@ extern "C" int miseg_head_local_bwd_rows(void* stream, int dt, const void* feat,
     return miseg_head_local_bwd(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, base, gw, gb, ws, ws_bytes);
 }
 
+extern "C" int64_t miseg_head_local_bwd_recompute_supported(int dt, int64_t C, int64_t S, int64_t K) {
+    return head_bwd_wave_shape(dt == MISEG_F16 ? (int)MISEG_BF16 : dt, C, S, K);
+}
+
+// miseg_head_local_bwd_rows without the probabilities: the kernel computes them again from feat, w, bias (see miseg_hip.h)
+extern "C" int miseg_head_local_bwd_recompute(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
+                                              const int32_t* src, const int32_t* flips, int64_t M, const float* w, const float* bias, int64_t S,
+                                              int64_t K, float T, const float* gprob, void* gfeat_rows, int64_t row0, float* gw, float* gb,
+                                              void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_head_local_bwd_recompute, stream, dt, feat, B, H, W, C, src, flips, M, w, bias, S, K, T, gprob, gfeat_rows, row0, gw, gb, ws, ws_bytes);
+    MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd_recompute, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, bias, S, K, T, gprob, gfeat_rows, row0, gw, gb, ws, ws_bytes);
+    MISEG_REQUIRE(bias, "head_local_bwd_recompute: null bias");
+    MISEG_REQUIRE(row0 >= 0 && row0 < B, "head_local_bwd_recompute: bad first row");
+    void* base = gfeat_rows ? static_cast<char*>(gfeat_rows) - row0 * H * W * C * 2 : nullptr;
+    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, bias, S, K, T, nullptr, gprob, base, gw, gb, ws, ws_bytes, 0);
+}
+
 extern "C" int miseg_head_local_bwd_acc(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C,
                                         const int32_t* src, const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K,
                                         float T, const float* prob, const float* gprob, void* gfeat_inout, float* gw, float* gb, void* ws,
@@ -919,13 +1031,14 @@ extern "C" int miseg_head_local_bwd_acc(void* stream, int dt, const void* feat, 
     MISEG_TAPE(miseg_head_local_bwd_acc, stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes);
     MISEG_F16_DISPATCH_ON(dt, miseg_head_local_bwd_acc, stream, MISEG_BF16, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes);
     MISEG_REQUIRE(gfeat_inout, "head_local_bwd_acc: null gradient tensor");
-    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes, 1);
+    return head_local_bwd_impl(stream, dt, feat, B, H, W, C, src, flips, M, w, nullptr, S, K, T, prob, gprob, gfeat_inout, gw, gb, ws, ws_bytes, 1);
 }
 
 static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B, int64_t H, int64_t W, int64_t C, const int32_t* src,
-                               const int32_t* flips, int64_t M, const float* w, int64_t S, int64_t K, float T, const float* prob,
-                               const float* gprob, void* gfeat, float* gw, float* gb, void* ws, int64_t ws_bytes, int accumulate) {
-    MISEG_REQUIRE(feat && src && w && prob && gprob && gw && gb && ws, "head_local_bwd: null pointer");
+                               const int32_t* flips, int64_t M, const float* w, const float* bias, int64_t S, int64_t K, float T,
+                               const float* prob, const float* gprob, void* gfeat, float* gw, float* gb, void* ws, int64_t ws_bytes, int accumulate) {
+    MISEG_REQUIRE(feat && src && w && (prob || bias) && gprob && gw && gb && ws, "head_local_bwd: null pointer");
+    MISEG_REQUIRE(!bias || head_bwd_wave_shape(dt, C, S, K), "head_local_bwd_recompute: bf16 / f16 features, C = 16, S = 5, K = 20 only");
     MISEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 128 && K > 0 && K <= 64 && S * K <= 256 && M > 0, "head_local_bwd: need C%%4==0, C<=128, S*K<=256");
     MISEG_REQUIRE(ws_bytes >= miseg_head_local_bwd_ws_bytes(M, H, W, C, S, K), "head_local_bwd: workspace too small");
     MISEG_REQUIRE(S * M * K * H * W * 4 < ((int64_t)1 << 32), "head_local_bwd: prob larger than 4 GiB (32-bit buffer offsets)");
@@ -940,16 +1053,24 @@ static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B
     }
     MISEG_REQUIRE(lds <= 150 * 1024, "head_local_bwd: S*K*C too large for LDS");
     if (head_bwd_wave_shape(dt, C, S, K)) {
-        constexpr int wave_lds = (2 * 64 * 24 + 2 * 20 * 72 + 16 * 72) * 2;
+        constexpr int wave_lds = (2 * 64 * 24 + 16 * 72) * 2, wave_lds_r = wave_lds + 20 * 68 * 4;      // the kernel's WAVE_LDS
         const size_t wl = (size_t)4 * wave_lds + (size_t)S * 2 * 16 * 32 * 2;
-        hipFuncSetAttribute((const void*)head_local_bwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+        const size_t wlr = (size_t)4 * wave_lds_r + (size_t)S * 2 * 16 * 32 * 2 + (size_t)S * 3 * 20 * 16 * 2 + (size_t)S * 20 * 4;   // + W in three planes, bias
+        hipFuncSetAttribute(bias ? (const void*)head_local_bwd_wave_kernel<16, true> : (const void*)head_local_bwd_wave_kernel<16, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bias ? wlr : wl));
         // one block per CU: alone the kernel runs as fast with 256 blocks as with 768 (it is bound by the p / g read pattern, 256 B
         // per plane and wave, not by occupancy -- DESIGN.md section 7), and the smaller footprint leaves LDS and registers to the
         // main-stream kernels this side-stream kernel runs next to.
-        const int nb = std::min(256, nblk);
+        // The recomputing form moves half the bytes and issues a third more instructions per chunk: two blocks per CU (what its LDS allows).
+        static const int nb_cap = [] { const char* e = getenv("MISEG_HEAD_BWD_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();   // diagnostic
+        const int nb = std::min(nb_cap ? nb_cap : bias ? 512 : 256, nblk);
         nused = nb;   // the final reduction reads this kernel's nb partials only
-        hipLaunchKernelGGL(head_local_bwd_wave_kernel<16>, dim3(nb), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
-                           (int)M, w, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials, accumulate);
+        if (bias)
+            hipLaunchKernelGGL((head_local_bwd_wave_kernel<16, true>), dim3(nb), dim3(256), wlr, st, (const bf16*)feat, (int)H, (int)W, src, flips,
+                               (int)M, w, bias, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials, accumulate);
+        else
+            hipLaunchKernelGGL((head_local_bwd_wave_kernel<16, false>), dim3(nb), dim3(256), wl, st, (const bf16*)feat, (int)H, (int)W, src, flips,
+                               (int)M, w, bias, (int)S, 1.0f / T, prob, gprob, (bf16*)gfeat, partials, accumulate);
     } else
 #define HLB2(TT, CTM, RW, K20V, BFV)                                                                                                         \
     {                                                                                                                             \

@@ -71,13 +71,27 @@ int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const Jo
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad);
 size_t local_bwd_bf16_ws_bytes(int64_t K, int64_t pad, int64_t P);
 bool local_bwd_f8_supported(int64_t K, int64_t pad);
+// Operand planes of the f16 + fp8 backward (K = 20), one buffer: [slack][p16: maps x HW x 40 B][slack][p8l: maps x HW x 24 B][slack][p8h: same]
+// [slack] -- the kernel copies whole 70-pixel row segments, which start up to 3 pixels before a row and end up to 69 after it.
+struct MiPlanes {
+    unsigned char *p16, *p8l, *p8h;
+};
+constexpr int64_t kPlaneSlack = 4096;
+static inline int64_t mi_planes_bytes(int64_t maps, int64_t HW) { return maps * HW * 88 + 4 * kPlaneSlack; }
+static inline MiPlanes mi_planes(unsigned char* base, int64_t maps, int64_t HW) {
+    if (!base) return MiPlanes{nullptr, nullptr, nullptr};
+    unsigned char* p16 = base + kPlaneSlack;
+    unsigned char* p8l = p16 + maps * HW * 40 + kPlaneSlack;
+    return MiPlanes{p16, p8l, p8l + maps * HW * 24 + kPlaneSlack};
+}
+int launch_make_planes(hipStream_t st, const float* probs, int64_t maps, int64_t HW, unsigned char* planes);
 size_t local_bwd_f8_ws_bytes(int64_t K, int64_t pad, int64_t P);
 int launch_local_bwd_f8(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                         int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
-                        int accumulate, void* ws);
+                        int accumulate, void* ws, const unsigned char* planes);
 
 int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                           int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
-                          int accumulate, void* ws, int nterms);
+                          int accumulate, void* ws, int nterms, const unsigned char* planes = nullptr);
 
 }  // namespace miseg

@@ -734,6 +734,42 @@ extern "C" int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64
     return MISEG_OK;
 }
 
+// ---- operand planes of the f16 + fp8 backward (see miseg_hip.h)
+extern "C" int64_t miseg_iic_local_planes_bytes(int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad) {
+    if (S <= 0 || UB <= 0 || H <= 0 || W <= 0 || !local_bwd_f8_supported(K, pad) || !local_bwd_bf16_supported(UB, K, H, W, pad)) return 0;
+    if (S * 2 * UB * H * W * 40 >= ((int64_t)1 << 32)) return 0;
+    return mi_planes_bytes(S * 2 * UB, H * W);
+}
+
+extern "C" int miseg_iic_local_make_planes(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad,
+                                           void* planes, int64_t planes_bytes) {
+    MISEG_TAPE(miseg_iic_local_make_planes, stream, probs, S, UB, K, H, W, pad, planes, planes_bytes);
+    MISEG_REQUIRE(probs && planes, "iic_local_make_planes: null pointer");
+    const int64_t need = miseg_iic_local_planes_bytes(S, UB, K, H, W, pad);
+    MISEG_REQUIRE(need > 0, "iic_local_make_planes: K = 20, pad = 3 only");
+    MISEG_REQUIRE(planes_bytes >= need, "iic_local_make_planes: buffer %ld < %ld", (long)planes_bytes, (long)need);
+    launch_make_planes(as_stream(stream), probs, S * 2 * UB, H * W, static_cast<unsigned char*>(planes));
+    MISEG_LAUNCH_CHECK("make_planes_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int miseg_iic_local_bwd_heads_planes(void* stream, const void* planes, int64_t planes_bytes, int64_t S, int64_t UB, int64_t K, int64_t H,
+                                                int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
+                                                float* gprob, int accumulate, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_iic_local_bwd_heads_planes, stream, planes, planes_bytes, S, UB, K, H, W, pad, win, P, grad_raw, scale, gprob, accumulate, ws, ws_bytes);
+    MISEG_REQUIRE(planes && win && grad_raw && scale && gprob && ws, "iic_local_bwd_heads_planes: null pointer");
+    MISEG_REQUIRE(P > 0, "iic_local_bwd_heads_planes: bad shape");
+    const int64_t need = miseg_iic_local_planes_bytes(S, UB, K, H, W, pad);
+    MISEG_REQUIRE(need > 0, "iic_local_bwd_heads_planes: K = 20, pad = 3 only");
+    MISEG_REQUIRE(planes_bytes >= need, "iic_local_bwd_heads_planes: plane buffer %ld < %ld", (long)planes_bytes, (long)need);
+    MISEG_REQUIRE(ws_bytes >= (int64_t)local_bwd_bf16_ws_bytes(K, pad, P * S), "iic_local_bwd_heads_planes: workspace too small");
+    const int64_t hs = 2 * UB * K * H * W, half = UB * K * H * W;
+    launch_local_bwd_rows(as_stream(stream), nullptr, nullptr, S, hs, UB, K, H, W, pad, win, P, grad_raw, scale, gprob, gprob + half, accumulate, ws, 2,
+                          static_cast<const unsigned char*>(planes));
+    MISEG_LAUNCH_CHECK("local_bwd_f8_kernel");
+    return MISEG_OK;
+}
+
 extern "C" int64_t miseg_iic_local_bwd_ws_bytes(int64_t K, int64_t pad, int64_t P) {
     return (int64_t)local_bwd_bf16_ws_bytes(K, pad, P) + 16;
 }

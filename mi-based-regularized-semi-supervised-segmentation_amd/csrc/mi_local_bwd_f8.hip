@@ -115,6 +115,53 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     return (unsigned)w;
 }
 
+// Four probabilities -> their operand images: f16 hi (4 x 2 B), e4m3(2^20 (v - hi)) and e4m3(2^8 v) (4 x 1 B each).  ONE definition for
+// the in-kernel split, the stand-alone plane writer below and the joint forward's by-product, so the three agree bit for bit.
+__device__ __forceinline__ void split_quad(const float* v, qu32x2& h16, unsigned& l8, unsigned& h8) {
+    const qh2_t h01 = {(_Float16)v[0], (_Float16)v[1]}, h23 = {(_Float16)v[2], (_Float16)v[3]};
+    h16 = qu32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    l8 = pack_fp8x4((v[0] - (float)h01[0]) * 1048576.f, (v[1] - (float)h01[1]) * 1048576.f, (v[2] - (float)h23[0]) * 1048576.f,
+                    (v[3] - (float)h23[1]) * 1048576.f);
+    h8 = pack_fp8x4(v[0] * 256.f, v[1] * 256.f, v[2] * 256.f, v[3] * 256.f);
+}
+
+// ---- operand planes in memory (miseg_hip.h: "local-MI operand planes"): per map and pixel the three images a source row of the backward
+// is made of, pixel-major, so that a row of the kernel's LDS buffer is a plain copy of 70 consecutive pixels of each plane.
+//   p16 [map][H][W][20] f16      p8l, p8h [map][H][W][24] e4m3 (classes 20..23 zero)
+__global__ __launch_bounds__(256) void make_planes_kernel(const float* __restrict__ probs, int maps, int HW, unsigned char* __restrict__ p16,
+                                                          unsigned char* __restrict__ p8l, unsigned char* __restrict__ p8h) {
+    constexpr int K = 20;
+    const int pix = blockIdx.x * 256 + threadIdx.x, map = blockIdx.y;
+    if (pix >= HW || map >= maps) return;
+    const float* src = probs + (size_t)map * K * HW + pix;
+    const size_t at = (size_t)map * HW + pix;
+    unsigned h[10], l[6], g[6];
+#pragma unroll
+    for (int c4 = 0; c4 < K; c4 += 4) {
+        const float v[4] = {src[(size_t)c4 * HW], src[(size_t)(c4 + 1) * HW], src[(size_t)(c4 + 2) * HW], src[(size_t)(c4 + 3) * HW]};
+        qu32x2 hh;
+        split_quad(v, hh, l[c4 / 4], g[c4 / 4]);
+        h[c4 / 2] = hh[0], h[c4 / 2 + 1] = hh[1];
+    }
+    l[5] = 0u, g[5] = 0u;
+    qu32x2* o16 = reinterpret_cast<qu32x2*>(p16 + at * 40);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o16[i] = qu32x2{h[2 * i], h[2 * i + 1]};
+    qu32x2* ol = reinterpret_cast<qu32x2*>(p8l + at * 24);
+    qu32x2* oh = reinterpret_cast<qu32x2*>(p8h + at * 24);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ol[i] = qu32x2{l[2 * i], l[2 * i + 1]}, oh[i] = qu32x2{g[2 * i], g[2 * i + 1]};
+}
+
+// 16 bytes per lane, memory -> LDS without a register in between: lane i's bytes land at lds_dst + 16 i (lds_dst wave-uniform).  The
+// compiler does not count this load: the caller waits for it (s_waitcnt vmcnt) before the wave reads the bytes.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // value(m = (tau,o), beta, c) of direction dir, pre-scaled
 template <int K, int PAD>
 __device__ __forceinline__ float g_value(const float* __restrict__ grad_raw, int p, int dir, int m, int beta, int c, float inv) {
@@ -161,12 +208,18 @@ __global__ void pack_g_f8_kernel(const float* __restrict__ grad_raw, const float
     }
 }
 
-template <int K, int PAD, bool ACC, int NTW, int WAVES>
+// PL: the source rows come from the operand planes (x, y unused): a row is seven 16-byte-per-lane copies memory -> LDS, issued as soon
+// as the phase that reads the plane's previous row is over and waited for where the next row's phase begins -- no registers, no
+// conversions, no exposed round trip (the register loader has to fetch AFTER the row's MFMAs: 40 live registers do not fit beside
+// 180 accumulators).  Pixels outside the window are zeroed in LDS once the copy has landed (strips on a window edge only).
+template <int K, int PAD, bool ACC, int NTW, int WAVES, bool PL>
 __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float* __restrict__ x, const float* __restrict__ y, Rows8Geom g,
                                                               const int32_t* __restrict__ win,
                                                               const unsigned char* __restrict__ gpack, const float* __restrict__ gexp,
                                                               const float* __restrict__ scale, float* __restrict__ gx,
-                                                              float* __restrict__ gy, unsigned long long* __restrict__ stamps) {
+                                                              float* __restrict__ gy, unsigned long long* __restrict__ stamps,
+                                                              const unsigned char* __restrict__ pl16, const unsigned char* __restrict__ pl8l,
+                                                              const unsigned char* __restrict__ pl8h) {
     typedef Q3<K, PAD, NTW> C;
     constexpr int T = C::T, RT = C::RT, NT = C::NT, KS = C::KS, NI = C::NI, MP = C::MP, CS = C::CS, CS8 = C::CS8;
     constexpr int BWB = C::B16P + 2 * C::B8P;            // bytes of one wave's source-row buffer: f16 plane, 8-bit lo plane, 8-bit hi plane
@@ -267,15 +320,71 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                 unsigned char* p8h = p8l + C::B8P;
 #pragma unroll
                 for (int c4 = 0; c4 < K; c4 += 4) {
-                    qh2_t h01 = {(_Float16)v[c4], (_Float16)v[c4 + 1]}, h23 = {(_Float16)v[c4 + 2], (_Float16)v[c4 + 3]};
-                    float l[4] = {v[c4] - (float)h01[0], v[c4 + 1] - (float)h01[1], v[c4 + 2] - (float)h23[0], v[c4 + 3] - (float)h23[1]};
-                    *reinterpret_cast<qu32x2*>(p16 + c4 * 2) = qu32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-                    *reinterpret_cast<unsigned*>(p8l + c4) = pack_fp8x4(l[0] * 1048576.f, l[1] * 1048576.f, l[2] * 1048576.f, l[3] * 1048576.f);
-                    *reinterpret_cast<unsigned*>(p8h + c4) = pack_fp8x4(v[c4] * 256.f, v[c4 + 1] * 256.f, v[c4 + 2] * 256.f, v[c4 + 3] * 256.f);
+                    qu32x2 h16;
+                    unsigned l8, h8;
+                    split_quad(v + c4, h16, l8, h8);
+                    *reinterpret_cast<qu32x2*>(p16 + c4 * 2) = h16;
+                    *reinterpret_cast<unsigned*>(p8l + c4) = l8;
+                    *reinterpret_cast<unsigned*>(p8h + c4) = h8;
                 }
             };
             if (C::WS >= 64 || lane < C::WS) put(pfa, lane);
             if (TAIL && lane < C::WS - 64) put(pfb, 64 + lane);
+        };
+
+        // ---- PL: the planes' rows.  Row hsr of map (s, dir ? x : y, n), pixels col0 - PAD .. + 69: 2 800 bytes of p16 = 175 lanes x 16 B,
+        // 1 680 bytes of each 8-bit plane = 105.  A row outside the window is zeros, written by the wave itself.
+        const unsigned ldsBw = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bw;
+        const long long pix00 = ((long long)((long long)s * 2 * g.N + (dir ? 0 : g.N) + n) * g.H) * g.W + (col0 - PAD);
+        const bool edge = col0 - PAD < w0w || col0 - PAD + C::WS > w1w;        // wave-uniform: some of the row's pixels lie outside the window
+        auto row_in = [&](int hsr) { return hsr >= h0w && hsr < h1w; };
+        auto zero_span = [&](unsigned char* dst, int bytes) {
+            for (int i = lane * 16; i < bytes; i += 64 * 16) *reinterpret_cast<qu32x4*>(dst + i) = qu32x4{0u, 0u, 0u, 0u};
+        };
+        auto issue16 = [&](int hsr) {
+            static_assert(C::WS * CS * 2 == 2800 && C::B16P >= 2800 && C::B16P % 16 == 0, "row geometry of the f16 plane copy");
+            if (row_in(hsr)) {
+                const unsigned char* src = pl16 + (pix00 + (long long)hsr * g.W) * (CS * 2) + lane * 16;
+                glds16(src, ldsBw);
+                glds16(src + 1024, ldsBw + 1024);
+                if (lane < 175 - 128) glds16(src + 2048, ldsBw + 2048);
+            } else zero_span(Bw, C::B16P);
+        };
+        auto issue8 = [&](int hsr) {
+            static_assert(C::WS * CS8 == 1680 && C::B8P >= 1680 && C::B8P % 16 == 0, "row geometry of the 8-bit plane copies");
+            if (row_in(hsr)) {
+                const long long at = (pix00 + (long long)hsr * g.W) * CS8 + lane * 16;
+                glds16(pl8l + at, ldsBw + C::B16P);
+                if (lane < 105 - 64) glds16(pl8l + at + 1024, ldsBw + C::B16P + 1024);
+                glds16(pl8h + at, ldsBw + C::B16P + C::B8P);
+                if (lane < 105 - 64) glds16(pl8h + at + 1024, ldsBw + C::B16P + C::B8P + 1024);
+            } else zero_span(Bw + C::B16P, 2 * C::B8P);
+        };
+        // after the copy has landed: pixels outside the window's columns -> zeros (what the register loader's OOB loads return)
+        auto fix16 = [&]() {
+            if (!edge) return;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int pix = half * 64 + lane, col = col0 - PAD + pix;
+                if (pix < C::WS && (col < w0w || col >= w1w)) {
+#pragma unroll
+                    for (int i = 0; i < CS * 2; i += 8) *reinterpret_cast<qu32x2*>(Bw + pix * (CS * 2) + i) = qu32x2{0u, 0u};
+                }
+            }
+        };
+        auto fix8 = [&]() {
+            if (!edge) return;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int pix = half * 64 + lane, col = col0 - PAD + pix;
+                if (pix < C::WS && (col < w0w || col >= w1w)) {
+#pragma unroll
+                    for (int i = 0; i < CS8; i += 8) {
+                        *reinterpret_cast<qu32x2*>(Bw + C::B16P + pix * CS8 + i) = qu32x2{0u, 0u};
+                        *reinterpret_cast<qu32x2*>(Bw + C::B16P + C::B8P + pix * CS8 + i) = qu32x2{0u, 0u};
+                    }
+                }
+            }
         };
 
         f32x4 acc[T][NT], rem[RT][NT];
@@ -289,8 +398,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
             for (int nt = 0; nt < NT; ++nt) rem[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         const int hs_first = r0 - PAD, hs_last = r1 - 1 + PAD;
-        fetch_row(hs_first);
-        commit_row();
+        if constexpr (PL) {
+            issue16(hs_first);
+            issue8(hs_first);
+            wait_vm<0>();
+            fix16();
+            fix8();
+        } else {
+            fetch_row(hs_first);
+            commit_row();
+        }
         const int aoff = (l15 * 32 + 8 * (q ^ ((0 - (l15 >> 2)) & 3)));       // this lane's 16 B inside a main M tile of the f16 image (elements)
         // f16 B fragment of k-step ks = two 4-blocks k = 32 ks + 8 q + 4 hf .. + 3 of (beta, c) = (k / 20, k % 20) at pixel l15 + beta:
         // pixel-major rows of exactly 20 classes make that the byte address 40 l15 + 2 k -- one lane register plus immediates.  Steps past
@@ -367,6 +484,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
                 const int hj = hsr + PAD - (ph - j) % T;
                 open_row[j] = hj >= r0 && hj < r1;
             }
+            if constexpr (PL) {
+                if (hsr > hs_first) {          // this row's f16 plane, issued after the previous row's phase 1; its four 8-bit copies may still fly
+                    wait_vm<4>();
+                    fix16();
+                }
+            }
             F8_STAMP(st_fetch)
             {
                 // ---- phase 1: hi x hi on the f16 pipe; edge slots (output row outside the unit) skipped behind a wave-uniform branch per tile
@@ -399,6 +522,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
             }
             F8_STAMP(st_p1)
             __builtin_amdgcn_sched_barrier(0);            // phase 2's first fragment loads stay behind phase 1's last MFMAs (they would not fit beside its registers)
+            if constexpr (PL) {
+                const bool more = hsr < hs_last;
+                if (more) issue16(hsr + 1);               // the f16 plane is free: the next row's copy flies during phase 2
+                if (hsr > hs_first) {                     // this row's 8-bit planes, issued after the previous row's stores
+                    if (more && row_in(hsr + 1)) wait_vm<3>(); else wait_vm<0>();
+                    fix8();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             {
                 // ---- phase 2: both cross terms, K-concatenated, on the block-scaled fp8 pipe
                 qi8_t a8q[2], b8[NT];
@@ -480,8 +612,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
 #endif
 #if !(MISEG_F8_ABL & 1)
             if (hsr < hs_last) {
-                fetch_row(hsr + 1);                        // this row's B reads are done (same wave: program order)
-                commit_row();
+                if constexpr (PL) issue8(hsr + 1);         // behind the stores: `vmcnt(4)` at the top of the next row then covers stores + f16 copies
+                else {
+                    fetch_row(hsr + 1);                    // this row's B reads are done (same wave: program order)
+                    commit_row();
+                }
             }
 #endif
         }
@@ -505,7 +640,7 @@ bool local_bwd_f8_supported(int64_t K, int64_t pad) { return K == 20 && pad == 3
 
 int launch_local_bwd_f8(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                         int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
-                        int accumulate, void* ws) {
+                        int accumulate, void* ws, const unsigned char* planes) {
     typedef Q3<20, 3, 4> C;
     constexpr int WAVES = 8;
     Rows8Geom g{(int)N, (int)H, (int)W, (int)P, (int)S, accumulate, 256, (long long)hs};
@@ -516,13 +651,26 @@ int launch_local_bwd_f8(hipStream_t st, const float* x, const float* y, int64_t 
     const int total = PS * 2 * (C::KS * C::MP * 32 + C::NI * 8 * C::MP * 4);
     hipLaunchKernelGGL((pack_g_f8_kernel<20, 3>), dim3((total + 255) / 256), dim3(256), 0, st, grad_raw, gexp, PS, gpack);
     const size_t lds = (size_t)C::A16B + C::A8B + (size_t)WAVES * (C::B16P + 2 * C::B8P);
+    const MiPlanes pl = mi_planes(const_cast<unsigned char*>(planes), S * 2 * N, H * W);
     auto go = [&](auto kernel) {
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, dim3(g.G), dim3(64 * WAVES), lds, st, x, y, g, win, gpack, gexp, scale, gx, gy,
-                           reinterpret_cast<unsigned long long*>(gpack + (size_t)PS * 2 * (C::A16B + C::A8B)));
+                           reinterpret_cast<unsigned long long*>(gpack + (size_t)PS * 2 * (C::A16B + C::A8B)), pl.p16, pl.p8l, pl.p8h);
     };
-    if (g.accumulate) go(local_bwd_f8_kernel<20, 3, true, 4, WAVES>);
-    else go(local_bwd_f8_kernel<20, 3, false, 4, WAVES>);
+    if (planes) {
+        if (g.accumulate) go(local_bwd_f8_kernel<20, 3, true, 4, WAVES, true>);
+        else go(local_bwd_f8_kernel<20, 3, false, 4, WAVES, true>);
+    } else {
+        if (g.accumulate) go(local_bwd_f8_kernel<20, 3, true, 4, WAVES, false>);
+        else go(local_bwd_f8_kernel<20, 3, false, 4, WAVES, false>);
+    }
+    return 0;
+}
+
+int launch_make_planes(hipStream_t st, const float* probs, int64_t maps, int64_t HW, unsigned char* planes) {
+    const MiPlanes pl = mi_planes(planes, maps, HW);
+    hipLaunchKernelGGL(make_planes_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)maps), dim3(256), 0, st, probs, (int)maps, (int)HW, pl.p16, pl.p8l,
+                       pl.p8h);
     return 0;
 }
 

@@ -429,9 +429,9 @@ static int launch_rows(hipStream_t st, const float* x, const float* y, RowsGeom 
 
 int launch_local_bwd_rows(hipStream_t st, const float* x, const float* y, int64_t S, int64_t hs, int64_t N, int64_t K, int64_t H, int64_t W,
                           int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale, float* gx, float* gy,
-                          int accumulate, void* ws, int nterms) {
+                          int accumulate, void* ws, int nterms, const unsigned char* planes) {
     if (nterms == 2) {        // f16 hi x hi + fp8 cross terms where that kernel exists (pad 3), the bf16 split elsewhere
-        if (local_bwd_f8_supported(K, pad)) return launch_local_bwd_f8(st, x, y, S, hs, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws);
+        if (local_bwd_f8_supported(K, pad)) return launch_local_bwd_f8(st, x, y, S, hs, N, K, H, W, pad, win, P, grad_raw, scale, gx, gy, accumulate, ws, planes);
         nterms = 3;
     }
     RowsGeom g{(int)N, (int)H, (int)W, (int)P, (int)S, accumulate, 256, (long long)hs};

@@ -542,6 +542,9 @@ def _stacked_grad(params, shape, device) -> Tensor:
     return slot.view(shape) if slot is not None else torch.empty(shape, dtype=torch.float32, device=device)
 
 
+_HEAD_RECOMPUTE = os.environ.get("MISEG_HEAD_RECOMPUTE", "1") != "0"   # 0: the head backward reads the saved probabilities
+
+
 class _LocalHead(torch.autograd.Function):
     """S x (1x1 conv + channel softmax) with fused sample gather + flip replay -> prob [S,M,K,H,W]."""
 
@@ -561,14 +564,14 @@ class _LocalHead(torch.autograd.Function):
         call("miseg_head_local_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), _ptr(b),
              s, k, float(temperature), _ptr(prob), 2e-4, _ptr(viol), work=(2.0 * s * k * c * m * h * wd, (s * k * 4.0 + c * feat.element_size()) * m * h * wd),
              tag=f"head_local_fwd[c{c}]")
-        ctx.save_for_backward(feat, w, src, flips, prob)
+        ctx.save_for_backward(feat, w, src, flips, prob, b)
         ctx.temperature = float(temperature)
         ctx.src_range = getattr(src, "_miseg_range", None)
         return prob
 
     @staticmethod
     def backward(ctx, gprob: Tensor):
-        feat, w, src, flips, prob = ctx.saved_tensors
+        feat, w, src, flips, prob, b = ctx.saved_tensors
         bsz, c, h, wd = feat.shape
         s, k, _ = w.shape
         m = src.numel()
@@ -619,7 +622,12 @@ class _LocalHead(torch.autograd.Function):
         gb = _stacked_grad(ctx.stack_params[1], (s, k), feat.device)
         ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
         work = (4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 2 * c * feat.element_size()) * m * h * wd)
-        if compact:
+        if compact and _HEAD_RECOMPUTE and query("miseg_head_local_bwd_recompute_supported", _DT[feat.dtype], c, s, k):
+            # the kernel computes the probabilities again from the features (bit-equal to the forward's): it reads gprob only
+            call("miseg_head_local_bwd_recompute", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w),
+                 _ptr(b), s, k, ctx.temperature, _ptr(gprob), _ptr(gfeat), n0, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
+                 work=(work[0] + 2.0 * s * k * c * m * h * wd, work[1] - s * k * 4.0 * m * h * wd), tag=f"head_local_bwd[c{c}]")
+        elif compact:
             call("miseg_head_local_bwd_rows", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), s, k,
                  ctx.temperature, _ptr(prob), _ptr(gprob), _ptr(gfeat), n0, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), work=work,
                  tag=f"head_local_bwd[c{c}]")

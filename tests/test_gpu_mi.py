@@ -589,6 +589,47 @@ def test_local_head_backward_zero_fills_only_rows_outside_a_known_source_range(c
     assert float(grads[0][2:6].float().abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("h,w_", [(24, 40), (22, 36), (64, 64)])
+def test_local_head_backward_recomputing_the_probabilities_is_bit_equal(dtype, h, w_):
+    """miseg_head_local_bwd_recompute (the top tap's shipped backward: no probabilities read, the kernel redoes the forward's
+    W-planes x features MFMA + softmax) against miseg_head_local_bwd_rows on the forward's saved probabilities: the recomputed
+    p is the forward's p bit for bit, so gfeat / gw / gb must be IDENTICAL.  Ragged sizes (h*w % 64 != 0), all four flips."""
+    from miseg_amd import _cabi
+    torch.manual_seed(21)
+    bsz, c, s, k, temp = 7, 16, 5, 20, 0.7
+    dt = {torch.bfloat16: 1, torch.float16: 2}[dtype]
+    assert _cabi.query("miseg_head_local_bwd_recompute_supported", dt, c, s, k) == 1
+    assert _cabi.query("miseg_head_local_bwd_recompute_supported", dt, 32, s, k) == 0
+    feat = torch.randn(bsz, c, h, w_, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    wt, b = (torch.randn(s, k, c, device=DEV) * 0.3).contiguous(), torch.randn(s, k, device=DEV)
+    src = torch.arange(2, 6, dtype=torch.int32, device=DEV)
+    flips = torch.tensor([0, 3, 1, 2], dtype=torch.int32, device=DEV)
+    m, st = src.numel(), torch.cuda.current_stream().cuda_stream
+    prob = torch.empty(s, m, k, h, w_, device=DEV)
+    _cabi.call("miseg_head_local_fwd", st, dt, feat.data_ptr(), bsz, h, w_, c, src.data_ptr(), flips.data_ptr(), m, wt.data_ptr(), b.data_ptr(),
+               s, k, temp, prob.data_ptr(), 2e-4, 0)
+    gprob = torch.randn(prob.shape, device=DEV)
+    nb = _cabi.query("miseg_head_local_bwd_ws_bytes", m, h, w_, c, s, k)
+    outs = []
+    for recompute in (False, True):
+        gfeat = torch.full((m, c, h, w_), float("nan"), device=DEV, dtype=dtype).contiguous(memory_format=torch.channels_last)
+        gw, gb, ws = torch.empty_like(wt), torch.empty_like(b), torch.empty(nb, dtype=torch.uint8, device=DEV)
+        if recompute:
+            _cabi.call("miseg_head_local_bwd_recompute", st, dt, feat.data_ptr(), bsz, h, w_, c, src.data_ptr(), flips.data_ptr(), m, wt.data_ptr(),
+                       b.data_ptr(), s, k, temp, gprob.data_ptr(), gfeat.data_ptr(), 2, gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb)
+        else:
+            _cabi.call("miseg_head_local_bwd_rows", st, dt, feat.data_ptr(), bsz, h, w_, c, src.data_ptr(), flips.data_ptr(), m, wt.data_ptr(),
+                       s, k, temp, prob.data_ptr(), gprob.data_ptr(), gfeat.data_ptr(), 2, gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb)
+        outs.append((gfeat, gw, gb))
+    for a, r in zip(outs[0], outs[1]):
+        assert bool(torch.isfinite(r.float()).all()) and float(r.float().abs().max()) > 0.0
+        assert torch.equal(a, r)
+    with pytest.raises(_cabi.MisegError):      # another tap shape: refused, not silently computed by another kernel
+        _cabi.call("miseg_head_local_bwd_recompute", st, dt, feat.data_ptr(), bsz, h, w_ // 2, 32, src.data_ptr(), flips.data_ptr(), m, wt.data_ptr(),
+                   b.data_ptr(), s, k, temp, gprob.data_ptr(), gfeat.data_ptr(), 2, gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb)
+
+
 # ------------------------------------------------------------------------------------------ head variants (mlp / normalize)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("head_type,normalize", [("mlp", False), ("mlp", True), ("linear", True)])
