@@ -169,6 +169,9 @@ int miseg_iic_local_bwd_heads(void* stream, const float* probs, int64_t S, int64
 int64_t miseg_iic_local_planes_bytes(int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad);
 int miseg_iic_local_make_planes(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad,
                                 void* planes, int64_t planes_bytes);
+int miseg_iic_local_joint_fwd_heads_planes(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
+                                           int64_t pad, const int32_t* win, int64_t P, float* raw, void* ws, int64_t ws_bytes,
+                                           void* planes, int64_t planes_bytes);   /* = ..._joint_fwd_heads at precision 3 + the planes */
 int miseg_iic_local_bwd_heads_planes(void* stream, const void* planes, int64_t planes_bytes, int64_t S, int64_t UB, int64_t K, int64_t H,
                                      int64_t W, int64_t pad, const int32_t* win, int64_t P, const float* grad_raw, const float* scale,
                                      float* gprob, int accumulate, void* ws, int64_t ws_bytes);

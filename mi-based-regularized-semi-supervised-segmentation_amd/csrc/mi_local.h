@@ -67,10 +67,37 @@ static inline size_t joint_lds_bytes(const JointGeom& g) {
 // bf16 / f16 matrix-core paths of the joint (mi_local_fwd_px.hip) and of its backward (mi_local_bwd_rows.hip, mi_local_bwd_f8.hip).
 // nterms: 1 = plain bf16 operands, 3 = bf16 hi/lo split (three products), 2 = f16 hi x hi + fp8 cross terms (backward, pad 3)
 bool joint_fwd_bf16_supported(const JointGeom& g);
-int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& g, const int32_t* win, float* partials, int nterms);
+int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& g, const int32_t* win, float* partials, int nterms,
+                        unsigned char* planes = nullptr);
 bool local_bwd_bf16_supported(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad);
 size_t local_bwd_bf16_ws_bytes(int64_t K, int64_t pad, int64_t P);
 bool local_bwd_f8_supported(int64_t K, int64_t pad);
+typedef _Float16 qh8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 qh2_t __attribute__((ext_vector_type(2)));
+typedef int qi8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int qu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int qu32x2 __attribute__((ext_vector_type(2)));
+
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
+// Four probabilities -> their operand images: f16 hi (4 x 2 B), e4m3(2^20 (v - hi)) and e4m3(2^8 v) (4 x 1 B each).  ONE definition for
+// the in-kernel split, the stand-alone plane writer below and the joint forward's by-product, so the three agree bit for bit.
+__device__ __forceinline__ void split_quad(const float* v, qu32x2& h16, unsigned& l8, unsigned& h8) {
+    const qh2_t h01 = {(_Float16)v[0], (_Float16)v[1]}, h23 = {(_Float16)v[2], (_Float16)v[3]};
+    h16 = qu32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    l8 = pack_fp8x4((v[0] - (float)h01[0]) * 1048576.f, (v[1] - (float)h01[1]) * 1048576.f, (v[2] - (float)h23[0]) * 1048576.f,
+                    (v[3] - (float)h23[1]) * 1048576.f);
+    h8 = pack_fp8x4(v[0] * 256.f, v[1] * 256.f, v[2] * 256.f, v[3] * 256.f);
+}
+
+#endif
+
 // Operand planes of the f16 + fp8 backward (K = 20), one buffer: [slack][p16: maps x HW x 40 B][slack][p8l: maps x HW x 24 B][slack][p8h: same]
 // [slack] -- the kernel copies whole 70-pixel row segments, which start up to 3 pixels before a row and end up to 69 after it.
 struct MiPlanes {

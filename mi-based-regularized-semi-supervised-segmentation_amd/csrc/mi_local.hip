@@ -643,6 +643,8 @@ using namespace miseg;
 // precision (include/miseg_hip.h) -> products per fp32-class product: 1 = bf16x3, 2 = plain bf16, 3 = f16 + fp8 cross terms
 static inline int nterms_of(int precision) { return precision == 1 ? 3 : precision == 3 ? 2 : 1; }
 
+extern "C" int64_t miseg_iic_local_planes_bytes(int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W, int64_t pad);
+
 extern "C" int64_t miseg_iic_local_joint_ws_bytes(int64_t N, int64_t K, int64_t H, int64_t W, int64_t pad, int64_t P) {
     JointGeom g;
     if (N <= 0 || K <= 0 || P <= 0 || pad < 0 || !plan_joint(g, N, K, H, W, pad, P)) return -1;
@@ -708,6 +710,33 @@ extern "C" int miseg_iic_local_joint_fwd_heads(void* stream, const float* probs,
                                                  raw + s * P * TT * K * K, ws, ws_bytes, precision);
         if (rc != MISEG_OK) return rc;
     }
+    return MISEG_OK;
+}
+
+// the same at precision 3 (forward: bf16 hi / lo), and every probability it stages also leaves as the backward's operand planes
+extern "C" int miseg_iic_local_joint_fwd_heads_planes(void* stream, const float* probs, int64_t S, int64_t UB, int64_t K, int64_t H, int64_t W,
+                                                      int64_t pad, const int32_t* win, int64_t P, float* raw, void* ws, int64_t ws_bytes,
+                                                      void* planes, int64_t planes_bytes) {
+    MISEG_TAPE(miseg_iic_local_joint_fwd_heads_planes, stream, probs, S, UB, K, H, W, pad, win, P, raw, ws, ws_bytes, planes, planes_bytes);
+    MISEG_REQUIRE(probs && win && raw && ws && planes, "iic_local_joint_fwd_heads_planes: null pointer");
+    MISEG_REQUIRE(P > 0, "iic_local_joint_fwd_heads_planes: bad shape");
+    const int64_t need = miseg_iic_local_planes_bytes(S, UB, K, H, W, pad);
+    MISEG_REQUIRE(need > 0, "iic_local_joint_fwd_heads_planes: K = 20, pad = 3 only");
+    MISEG_REQUIRE(planes_bytes >= need, "iic_local_joint_fwd_heads_planes: plane buffer %ld < %ld", (long)planes_bytes, (long)need);
+    const int64_t hs = 2 * UB * K * H * W, TT = (2 * pad + 1) * (2 * pad + 1);
+    JointGeom g;
+    MISEG_REQUIRE(plan_joint(g, UB, K, H, W, pad, P * S) && joint_fwd_bf16_supported(g), "iic_local_joint_fwd_heads_planes: shape not supported");
+    MISEG_REQUIRE(ws_bytes >= miseg_iic_local_joint_ws_bytes(UB, K, H, W, pad, P * S), "iic_local_joint_fwd_heads_planes: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int cap = g.tilesM <= 4 ? 4 : 9;
+    JointGeom gh = g;
+    gh.P = (int)P; gh.S = (int)S; gh.hs = hs;
+    MISEG_REQUIRE(launch_joint_fwd_px(st, probs, probs + UB * K * H * W, gh, win, (float*)ws, 3, static_cast<unsigned char*>(planes)) == 0,
+                  "iic_local_joint_fwd_heads_planes: no kernel for this shape");
+    MISEG_LAUNCH_CHECK("joint_fwd_px_kernel");
+    const int64_t total = P * S * TT * K * K;
+    hipLaunchKernelGGL(joint_reduce_kernel, dim3(reduce_grid(total, g.G)), dim3(256), 0, st, (const float*)ws, g, cap, raw);
+    MISEG_LAUNCH_CHECK("joint_reduce_kernel");
     return MISEG_OK;
 }
 

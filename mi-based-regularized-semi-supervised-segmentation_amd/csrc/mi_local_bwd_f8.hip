@@ -68,12 +68,6 @@
 
 namespace miseg {
 
-typedef _Float16 qh8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 qh2_t __attribute__((ext_vector_type(2)));
-typedef int qi8_t __attribute__((ext_vector_type(8)));
-typedef unsigned int qu32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int qu32x2 __attribute__((ext_vector_type(2)));
-
 template <int K, int PAD, int NT_ = 4>
 struct Q3 {
     static_assert(K == 20, "Q3: the 16 + 4 channel split is written for K = 20");
@@ -107,22 +101,6 @@ __global__ __launch_bounds__(1024) void gexp_kernel(const float* __restrict__ gr
         for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
         gexp[blockIdx.x] = (m > 0.f && m < 3.0e38f) ? ldexpf(1.f, ilogbf(m)) : 1.f;
     }
-}
-
-__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (unsigned)w;
-}
-
-// Four probabilities -> their operand images: f16 hi (4 x 2 B), e4m3(2^20 (v - hi)) and e4m3(2^8 v) (4 x 1 B each).  ONE definition for
-// the in-kernel split, the stand-alone plane writer below and the joint forward's by-product, so the three agree bit for bit.
-__device__ __forceinline__ void split_quad(const float* v, qu32x2& h16, unsigned& l8, unsigned& h8) {
-    const qh2_t h01 = {(_Float16)v[0], (_Float16)v[1]}, h23 = {(_Float16)v[2], (_Float16)v[3]};
-    h16 = qu32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-    l8 = pack_fp8x4((v[0] - (float)h01[0]) * 1048576.f, (v[1] - (float)h01[1]) * 1048576.f, (v[2] - (float)h23[0]) * 1048576.f,
-                    (v[3] - (float)h23[1]) * 1048576.f);
-    h8 = pack_fp8x4(v[0] * 256.f, v[1] * 256.f, v[2] * 256.f, v[3] * 256.f);
 }
 
 // ---- operand planes in memory (miseg_hip.h: "local-MI operand planes"): per map and pixel the three images a source row of the backward

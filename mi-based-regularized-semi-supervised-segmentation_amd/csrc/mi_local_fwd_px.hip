@@ -73,9 +73,13 @@ struct PxGeom {
     long long hs;
 };
 
-template <int PAD, int NTERMS, int ROLE>
+// PLW: every probability this kernel stages is also written out as the backward's operand planes (miseg_hip.h, "local-MI operand
+// planes"; mi_local.h split_quad): Y rows by the Y tasks, the strip's own 64 columns of the X rows by the X tasks -- each element of
+// the window at least once (rows on a segment boundary twice, with the same bytes).  Maps: x = s * 2N + n, y = s * 2N + N + n.
+template <int PAD, int NTERMS, int ROLE, bool PLW>
 __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const float* __restrict__ y, const PxGeom& g,
-                                              const int32_t* __restrict__ win, float* __restrict__ partials, unsigned char* lds) {
+                                              const int32_t* __restrict__ win, float* __restrict__ partials, unsigned char* lds,
+                                              const MiPlanes pln) {
     typedef PX<PAD> C;
     constexpr int K = C::K, T = C::T, RT = C::RT, MT = C::MT, NT = C::MT, NP = NTERMS == 1 ? 1 : 2, WT = C::WT, RING = C::RING, KS = C::KS;
     constexpr int CM = C::CM, CR = C::CR;
@@ -149,7 +153,7 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)tbytes, 0x00020000);
     unsigned loff[TPW], seg_so[TPW];                     // per segment: the lane's column (bytes, OOB if it has nothing to load); image + channel
-    auto seg_setup = [&](int n, int col0) {
+    auto seg_setup1 = [&](int n, int col0) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int col = tail[i] ? col0 - PAD + tl_px : (isY[i] ? col0 + lane : col0 - PAD + lane);
@@ -159,7 +163,7 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
         }
     };
     // rows ybase, ybase + 1 of Y and xbase, xbase + 1 of X (rows outside the window read zeros: OOB + anything stays out of range)
-    auto prefetch = [&](float (&pf)[TPW][4], int ybase, int xbase) {
+    auto prefetch1 = [&](float (&pf)[TPW][4], int ybase, int xbase) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int row = __builtin_amdgcn_readfirstlane((isY[i] ? ybase : xbase) + odd[i]);
@@ -179,7 +183,7 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
             }
         }
     };
-    auto commit = [&](float (&pf)[TPW][4], int ybase, int xpar) {
+    auto commit1 = [&](float (&pf)[TPW][4], int ybase, int xpar) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             if (!act[i]) continue;                        // wave-uniform
@@ -198,6 +202,114 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
         }
     };
 
+    // ---- PLW: the same rows through a second loader, dealt so that the plane stores are contiguous.  Wave w stages row kind w >> 1 (Y,
+    // Y + 1, X, X + 1), pixels 32 (w & 1) .. + 31; a lane is (pixel, half of its 20 channels): half 0 loads classes 0..11 (quads 0, 1, 2),
+    // half 1 classes 12..19 (quads 3, 4) -- and, in the first wave of an X row, quad ti % 5 of tail pixel 64 + ti / 5 in its spare four
+    // registers (ti = lane >> 1 < 10 PAD).  Loads stay coalesced (32 consecutive pixels per plane and half-wave); a pixel's 40 + 24 + 24
+    // plane bytes leave from two neighbouring lanes, 1 280 + 2 x 768 contiguous bytes per wave.  (With the task loader above the planes
+    // left as 8-byte pieces 40 bytes apart: +170 us on the cfg2 launch instead of +70.  Without the plane stores this loader is the
+    // slower one by 4 %: it is used for PLW only.)
+    static_assert(!PLW || NP == 2, "the plane by-product belongs to the three-term forward");
+    const int kind2 = wv >> 1, odd2 = kind2 & 1, half = lane & 1, pxl = (wv & 1) * 32 + (lane >> 1), ti = lane >> 1;
+    const bool isY2 = kind2 < 2, tailw = wv >= 4 && !(wv & 1), tlane = tailw && half && ti < 5 * 2 * PAD;
+    const int tp = 64 + ti / 5, tq = ti % 5;
+    const unsigned ldsYm = 0u, ldsYr = (unsigned)(NP * ymPlane) * 2u, ldsXm = ldsYr + (unsigned)(NP * yrPlane) * 2u, ldsXr = ldsXm + (unsigned)(NP * xmPlane) * 2u;
+    const unsigned bM = isY2 ? ldsYm : ldsXm, bR = isY2 ? ldsYr : ldsXr;
+    const unsigned strideM = (unsigned)(isY2 ? C::YROWM : C::XROWM) * 2u, strideR = (unsigned)(isY2 ? C::YROWR : C::XROWR) * 2u;
+    const unsigned loM = (unsigned)(isY2 ? ymPlane : xmPlane) * 2u, loR = (unsigned)(isY2 ? yrPlane : xrPlane) * 2u;
+    // quads A (0 | 3), B (1 | 4), C (2 | a tail quad): LDS byte address in row buffer 0 (hi plane), hi -> lo, buffer stride
+    const unsigned dA = bM + (unsigned)(pxl * CM + (half ? 12 : 0)) * 2u;
+    const unsigned dB = half ? bR + (unsigned)(pxl * CR) * 2u : bM + (unsigned)(pxl * CM + 4) * 2u;
+    const unsigned dC = half ? (tq < 4 ? ldsXm + (unsigned)(tp * CM + tq * 4) * 2u : ldsXr + (unsigned)(tp * CR) * 2u) : bM + (unsigned)(pxl * CM + 8) * 2u;
+    const unsigned loB = half ? loR : loM, sB = half ? strideR : strideM;
+    const unsigned loC = half ? (tq < 4 ? (unsigned)xmPlane * 2u : (unsigned)xrPlane * 2u) : loM;
+    const unsigned sC = half ? (tq < 4 ? (unsigned)C::XROWM * 2u : (unsigned)C::XROWR * 2u) : strideM;
+    const bool hasC = !half || tlane;
+    const unsigned nmaps = (unsigned)g.S * 2u * (unsigned)g.N;
+    const __amdgpu_buffer_rsrc_t rsP16 = __builtin_amdgcn_make_buffer_rsrc((void*)pln.p16, 0, PLW ? (int)(nmaps * (unsigned)plane * 40u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP8L = __builtin_amdgcn_make_buffer_rsrc((void*)pln.p8l, 0, PLW ? (int)(nmaps * (unsigned)plane * 24u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP8H = __builtin_amdgcn_make_buffer_rsrc((void*)pln.p8h, 0, PLW ? (int)(nmaps * (unsigned)plane * 24u) : 0, 0x00020000);
+    unsigned voA = OOB, voC = OOB, seg_so2 = 0u, pmap2 = 0u;                  // per segment: load offsets (bytes), image, first row of the map's planes
+    unsigned pv16 = OOB, pvC16 = OOB, pv8 = OOB, pvC8 = OOB, pvZ8 = OOB, pvZT = OOB;   // plane byte offsets inside a plane row (OOB: not this strip's pixel)
+    auto seg_setup2 = [&](int n, int col0) {
+        const int col = isY2 ? col0 + pxl : col0 - PAD + pxl, colT = col0 - PAD + tp;
+        const bool okc = col < w1 && (isY2 || col >= w0), okT = tlane && colT < w1 && colT >= w0;
+        const bool own = okc && col >= col0 && col < col0 + WT, ownT = okT && colT < col0 + WT;
+        voA = okc ? (unsigned)col * 4u + (half ? 12u : 0u) * pl4 : OOB;
+        voC = half ? (okT ? (unsigned)colT * 4u + (unsigned)(tq * 4) * pl4 : OOB) : (okc ? (unsigned)col * 4u + 8u * pl4 : OOB);
+        seg_so2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)n * (unsigned)K * pl4));
+        pmap2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((((unsigned)shead * 2u + (isY2 ? 1u : 0u)) * (unsigned)g.N + (unsigned)n) * (unsigned)g.H));
+        pv16 = own ? (unsigned)col * 40u + (half ? 24u : 0u) : OOB;
+        pvC16 = half ? (ownT ? (unsigned)colT * 40u + (unsigned)tq * 8u : OOB) : (own ? (unsigned)col * 40u + 16u : OOB);
+        pv8 = own ? (unsigned)col * 24u + (half ? 12u : 0u) : OOB;
+        pvC8 = half ? (ownT ? (unsigned)colT * 24u + (unsigned)tq * 4u : OOB) : (own ? (unsigned)col * 24u + 8u : OOB);
+        pvZ8 = half && own ? (unsigned)col * 24u + 20u : OOB;
+        pvZT = ownT && tq == 4 ? (unsigned)colT * 24u + 20u : OOB;
+    };
+    auto prefetch2 = [&](float (&pf)[TPW][4], int ybase, int xbase) {
+        const int row = __builtin_amdgcn_readfirstlane((isY2 ? ybase : xbase) + odd2);
+        const unsigned radd = (row >= h0 && row < h1) ? (unsigned)row * wb : OOB;
+        const unsigned va = voA + radd, vc = voC + radd;
+#ifdef MISEG_PX_NOLOAD
+        for (int j = 0; j < 12; ++j) pf[j >> 2][j & 3] = __uint_as_float(va + vc + j);
+        return;
+#endif
+        if (isY2) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                pf[j >> 2][j & 3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, (int)(j < 8 ? va : vc), (int)(seg_so2 + (unsigned)(j & 7) * pl4), 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                pf[j >> 2][j & 3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, (int)(j < 8 ? va : vc), (int)(seg_so2 + (unsigned)(j & 7) * pl4), 0));
+        }
+    };
+    auto commit2 = [&](float (&pf)[TPW][4], int ybase, int xpar, int xbase, bool storeX) {
+        const int row = __builtin_amdgcn_readfirstlane((isY2 ? ybase : xbase) + odd2);
+        const unsigned buf = (unsigned)__builtin_amdgcn_readfirstlane(isY2 ? (ybase + odd2 + 4 * RING) % RING : 2 * xpar + odd2);
+        if (row >= h0 && row < h1 && (isY2 || storeX)) {                      // wave-uniform: the row's operand planes
+            qu32x2 h16[3];
+            unsigned l8[3], h8[3];
+#pragma unroll
+            for (int qd = 0; qd < 3; ++qd) split_quad(pf[qd], h16[qd], l8[qd], h8[qd]);
+            const unsigned prow = (pmap2 + (unsigned)row) * (unsigned)g.W;
+            __builtin_amdgcn_raw_buffer_store_b128(qu32x4{h16[0][0], h16[0][1], h16[1][0], h16[1][1]}, rsP16, (int)pv16, (int)(prow * 40u), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(h16[2], rsP16, (int)pvC16, (int)(prow * 40u), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(qu32x2{l8[0], l8[1]}, rsP8L, (int)pv8, (int)(prow * 24u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(l8[2], rsP8L, (int)pvC8, (int)(prow * 24u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(0u, rsP8L, (int)pvZ8, (int)(prow * 24u), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(qu32x2{h8[0], h8[1]}, rsP8H, (int)pv8, (int)(prow * 24u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(h8[2], rsP8H, (int)pvC8, (int)(prow * 24u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(0u, rsP8H, (int)pvZ8, (int)(prow * 24u), 0);
+            if (tailw) {                                                      // wave-uniform: tail pixels that hold classes 16..19 -> their pad bytes
+                __builtin_amdgcn_raw_buffer_store_b32(0u, rsP8L, (int)pvZT, (int)(prow * 24u), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(0u, rsP8H, (int)pvZT, (int)(prow * 24u), 0);
+            }
+        }
+        unsigned hi[12], lo[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            hi[j] = f32_to_bf16_bits(pf[j >> 2][j & 3]);
+            lo[j] = f32_to_bf16_bits(pf[j >> 2][j & 3] - bf16_bits_to_f32((unsigned short)hi[j]));
+        }
+        unsigned char* a = lds + dA + buf * strideM;
+        unsigned char* b = lds + dB + buf * sB;
+        unsigned char* c = lds + dC + buf * sC;
+        *reinterpret_cast<pu32x2*>(a) = pu32x2{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
+        if (NP == 2) *reinterpret_cast<pu32x2*>(a + loM) = pu32x2{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
+        *reinterpret_cast<pu32x2*>(b) = pu32x2{hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
+        if (NP == 2) *reinterpret_cast<pu32x2*>(b + loB) = pu32x2{lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
+        if (hasC) {
+            *reinterpret_cast<pu32x2*>(c) = pu32x2{hi[8] | (hi[9] << 16), hi[10] | (hi[11] << 16)};
+            if (NP == 2) *reinterpret_cast<pu32x2*>(c + loC) = pu32x2{lo[8] | (lo[9] << 16), lo[10] | (lo[11] << 16)};
+        }
+    };
+    auto seg_setup = [&](int n, int col0) { if constexpr (PLW) seg_setup2(n, col0); else seg_setup1(n, col0); };
+    auto prefetch = [&](float (&pf)[TPW][4], int ybase, int xbase) { if constexpr (PLW) prefetch2(pf, ybase, xbase); else prefetch1(pf, ybase, xbase); };
+    auto commit = [&](float (&pf)[TPW][4], int ybase, int xpar, int xbase, bool storeX) {
+        if constexpr (PLW) commit2(pf, ybase, xpar, xbase, storeX); else commit1(pf, ybase, xpar);
+    };
+
 #pragma unroll 1
     for (int q0 = qlo; q0 < qhi;) {
         const int strip = q0 / pps, pr = q0 - strip * pps, n = strip / tc, ct = strip - n * tc;
@@ -211,8 +323,8 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
         for (int w2 = 0; w2 < PAD + 1; w2 += 2) {         // both register sets in flight: half as many exposed round trips
             prefetch(pfA, r0 - PAD + 2 * w2, r0);
             prefetch(pfB, r0 - PAD + 2 * w2 + 2, r0);
-            commit(pfA, r0 - PAD + 2 * w2, 0);
-            commit(pfB, r0 - PAD + 2 * w2 + 2, 0);
+            commit(pfA, r0 - PAD + 2 * w2, 0, r0, w2 == 0);
+            commit(pfB, r0 - PAD + 2 * w2 + 2, 0, r0, false);
         }
         __syncthreads();
         // One pair of image rows.  Its loads are for the pair AFTER next (global -> registers takes longer than one pair's MFMAs: with
@@ -297,7 +409,7 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
                     }
                 }
             }
-            if (more) commit(pfCommit, r + 2 + PAD, xpar ^ 1);
+            if (more) commit(pfCommit, r + 2 + PAD, xpar ^ 1, r + 2, true);
             __syncthreads();                              // next pair's rows visible; this pair's X buffers / oldest ring rows reusable
         };
         if (r0 + 2 < r1) prefetch(pfB, r0 + 2 + PAD, r0 + 2);
@@ -339,16 +451,16 @@ __device__ __forceinline__ void joint_px_body(const float* __restrict__ x, const
     for (int e = tid; e < DN * DN; e += kPT) out[e] = Ds[e];
 }
 
-template <int PAD, int NTERMS>
+template <int PAD, int NTERMS, bool PLW>
 __global__ __launch_bounds__(kPT, 1) void joint_fwd_px_kernel(const float* __restrict__ x, const float* __restrict__ y, PxGeom g,
-                                                              const int32_t* __restrict__ win, float* __restrict__ partials) {
+                                                              const int32_t* __restrict__ win, float* __restrict__ partials, MiPlanes pln) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch ((wave & 4) ? 3 - (wave & 3) : (wave & 3)) {
-        case 0: joint_px_body<PAD, NTERMS, 0>(x, y, g, win, partials, ldsb); break;
-        case 1: joint_px_body<PAD, NTERMS, 1>(x, y, g, win, partials, ldsb); break;
-        case 2: joint_px_body<PAD, NTERMS, 2>(x, y, g, win, partials, ldsb); break;
-        default: joint_px_body<PAD, NTERMS, 3>(x, y, g, win, partials, ldsb); break;
+        case 0: joint_px_body<PAD, NTERMS, 0, PLW>(x, y, g, win, partials, ldsb, pln); break;
+        case 1: joint_px_body<PAD, NTERMS, 1, PLW>(x, y, g, win, partials, ldsb, pln); break;
+        case 2: joint_px_body<PAD, NTERMS, 2, PLW>(x, y, g, win, partials, ldsb, pln); break;
+        default: joint_px_body<PAD, NTERMS, 3, PLW>(x, y, g, win, partials, ldsb, pln); break;
     }
 }
 
@@ -365,18 +477,23 @@ bool joint_fwd_bf16_supported(const JointGeom& g) {
     return (size_t)g.N * g.K * g.H * g.W * 4 < 0x40000000ull;                  // 32-bit buffer offsets with an out-of-range marker
 }
 
-int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& jg, const int32_t* win, float* partials, int nterms) {
+int launch_joint_fwd_px(hipStream_t st, const float* x, const float* y, const JointGeom& jg, const int32_t* win, float* partials, int nterms,
+                        unsigned char* planes) {
     if (nterms == 2) nterms = 3;     // the f16 + fp8 split exists for the backward only (mi_local_bwd_f8.hip)
     PxGeom g{jg.N, jg.H, jg.W, jg.P, jg.S, jg.G, jg.hs};
     dim3 grid(g.G, g.P * g.S), block(kPT);
-#define PXL(PADV, NT_)                                                                                                           \
-    {                                                                                                                            \
-        const size_t lb = px_lds<PADV>(nterms);                                                                                   \
-        hipFuncSetAttribute((const void*)joint_fwd_px_kernel<PADV, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);    \
-        hipLaunchKernelGGL((joint_fwd_px_kernel<PADV, NT_>), grid, block, lb, st, x, y, g, win, partials);                        \
+    const MiPlanes pln = mi_planes(planes, (int64_t)g.S * 2 * g.N, (int64_t)g.H * g.W);     // planes: the heads layout (x = probs, y = probs + N K H W)
+#define PXL(PADV, NT_, PLW_)                                                                                                           \
+    {                                                                                                                                  \
+        const size_t lb = px_lds<PADV>(nterms);                                                                                         \
+        hipFuncSetAttribute((const void*)joint_fwd_px_kernel<PADV, NT_, PLW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);    \
+        hipLaunchKernelGGL((joint_fwd_px_kernel<PADV, NT_, PLW_>), grid, block, lb, st, x, y, g, win, partials, pln);                   \
     }
-    if (jg.pad == 3) { if (nterms == 1) PXL(3, 1) else PXL(3, 3) }
-    else { if (nterms == 1) PXL(1, 1) else PXL(1, 3) }
+    if (planes) {
+        if (jg.pad != 3 || nterms != 3) return -1;
+        PXL(3, 3, true)
+    } else if (jg.pad == 3) { if (nterms == 1) PXL(3, 1, false) else PXL(3, 3, false) }
+    else { if (nterms == 1) PXL(1, 1, false) else PXL(1, 3, false) }
 #undef PXL
     return 0;
 }

@@ -282,6 +282,11 @@ def _local_loss(raw: Tensor, k: int, pad: int, p: int, lamda: float, loss: Tenso
         call("miseg_iic_local_loss_fwd", _stream(), _ptr(raw), k, pad, p, float(lamda), _ptr(loss), _ptr(grad_raw))
 
 
+# 1: the joint forward writes the backward's operand planes and the f16 + fp8 backward copies its source rows from them.  Built and
+# measured: the backward gains less inside the step (-0.06 ms) than the by-product costs the forward (+0.07 ms).
+_MI_PLANES = os.environ.get("MISEG_MI_PLANES", "0") == "1"
+
+
 class _LocalMIHeads(torch.autograd.Function):
     """All S sub-heads of one decoder tap in one node: probs[S, 2*UB, K, H, W] holds, per sub-head, the UB maps of the
     flipped features followed by the UB maps of the transformed image (ref semi_seg/epocher.py:264-272 evaluates the
@@ -299,28 +304,38 @@ class _LocalMIHeads(torch.autograd.Function):
         p, t, dev = len(windows), 2 * pad + 1, probs.device
         win = windows_tensor(windows, dev)
         raw = torch.empty(s, p, t, t, k, k, dtype=torch.float32, device=dev)
+        planes = None
         if mask is None:    # every sub-head in one launch
             ws = _ws(max(query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, p * s),
                          query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, p)), dev)   # batched launch | per-head fallback
             px = sum((a1 - a0) * (b1 - b0) for a0, a1, b0, b1 in windows)
-            call("miseg_iic_local_joint_fwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, pad, _ptr(win), p, _ptr(raw), _ptr(ws), ws.numel(),
-                 _mi_precision, work=(2.0 * k * k * t * t * ub * px * s, 2.0 * ub * k * px * 4 * s), tag=f"iic_local_joint_fwd[p{pad}]")
+            nplanes = query("miseg_iic_local_planes_bytes", s, ub, k, h, w, pad) if _MI_PLANES and _mi_precision == MI_PRECISIONS["f16f8"] else 0
+            if nplanes > 0:
+                # the joint forward also writes every probability out as the backward's operand images (f16 hi, two e4m3 planes,
+                # pixel-major): the backward's source rows are then plain memory -> LDS copies, and this node keeps the planes, not probs
+                planes = torch.empty(nplanes, dtype=torch.uint8, device=dev)
+                call("miseg_iic_local_joint_fwd_heads_planes", _stream(), _ptr(probs), s, ub, k, h, w, pad, _ptr(win), p, _ptr(raw), _ptr(ws),
+                     ws.numel(), _ptr(planes), nplanes, work=(2.0 * k * k * t * t * ub * px * s, 2.0 * ub * k * px * (4 + 4.4) * s),
+                     tag=f"iic_local_joint_fwd[p{pad}]")
+            else:
+                call("miseg_iic_local_joint_fwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, pad, _ptr(win), p, _ptr(raw), _ptr(ws), ws.numel(),
+                     _mi_precision, work=(2.0 * k * k * t * t * ub * px * s, 2.0 * ub * k * px * 4 * s), tag=f"iic_local_joint_fwd[p{pad}]")
         else:
             for i in range(s):
                 _local_fwd(probs[i, :ub], probs[i, ub:], mask, pad, windows, win, raw[i])
         loss = scalar_out((s, p), dev)
         grad_raw = torch.empty_like(raw)
         _local_loss(raw, k, pad, s * p, lamda, loss, grad_raw)
-        ctx.save_for_backward(probs, mask, grad_raw, win)
-        ctx.pad, ctx.windows, ctx.ub = pad, list(windows), ub
+        ctx.save_for_backward(planes if planes is not None else probs, mask, grad_raw, win)
+        ctx.pad, ctx.windows, ctx.ub, ctx.planes, ctx.shape = pad, list(windows), ub, planes is not None, tuple(probs.shape)
         return loss
 
     @staticmethod
     def backward(ctx, gloss: Tensor):
         probs, mask, grad_raw, win = ctx.saved_tensors
-        s, _, k, h, w = probs.shape
+        s, _, k, h, w = ctx.shape
         ub = ctx.ub
-        gprob = torch.empty_like(probs)
+        gprob = torch.empty(ctx.shape, dtype=torch.float32, device=probs.device)
         if not _is_whole(ctx.windows, h, w):
             fill_zero(gprob)
         scale = gloss.contiguous().float()
@@ -341,9 +356,14 @@ class _LocalMIHeads(torch.autograd.Function):
                     call("miseg_gather_rows", _stream(), _ptr(grad_raw), _ptr(ggrad), s, npw, len(grp), _ptr(idx), per)
                     call("miseg_gather_rows", _stream(), _ptr(scale), _ptr(gscale), s, npw, len(grp), _ptr(idx), 1)
                 px = sum((ctx.windows[i][1] - ctx.windows[i][0]) * (ctx.windows[i][3] - ctx.windows[i][2]) for i in grp)
-                call("miseg_iic_local_bwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, ctx.pad, _ptr(gwin), len(grp), _ptr(ggrad),
-                     _ptr(gscale), _ptr(gprob), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(),
-                     work=(4.0 * k * k * tt * ub * px * s, 4.0 * ub * k * px * 4 * s), tag=f"iic_local_bwd[p{ctx.pad}]")
+                if ctx.planes:
+                    call("miseg_iic_local_bwd_heads_planes", _stream(), _ptr(probs), probs.numel(), s, ub, k, h, w, ctx.pad, _ptr(gwin), len(grp),
+                         _ptr(ggrad), _ptr(gscale), _ptr(gprob), 0 if whole else 1, _ptr(bws), bws.numel(),
+                         work=(4.0 * k * k * tt * ub * px * s, 2.0 * ub * k * px * (4.4 + 4) * s), tag=f"iic_local_bwd[p{ctx.pad}]")
+                else:
+                    call("miseg_iic_local_bwd_heads", _stream(), _ptr(probs), s, ub, k, h, w, ctx.pad, _ptr(gwin), len(grp), _ptr(ggrad),
+                         _ptr(gscale), _ptr(gprob), 0 if whole else 1, _mi_precision, _ptr(bws), bws.numel(),
+                         work=(4.0 * k * k * tt * ub * px * s, 4.0 * ub * k * px * 4 * s), tag=f"iic_local_bwd[p{ctx.pad}]")
         else:
             for i in range(s):
                 _local_bwd(probs[i, :ub], probs[i, ub:], mask, ctx.pad, ctx.windows, win, grad_raw[i], scale[i], gprob[i, :ub],
@@ -564,7 +584,11 @@ class _LocalHead(torch.autograd.Function):
         call("miseg_head_local_fwd", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w), _ptr(b),
              s, k, float(temperature), _ptr(prob), 2e-4, _ptr(viol), work=(2.0 * s * k * c * m * h * wd, (s * k * 4.0 + c * feat.element_size()) * m * h * wd),
              tag=f"head_local_fwd[c{c}]")
-        ctx.save_for_backward(feat, w, src, flips, prob, b)
+        # the shipped top tap: the backward computes the probabilities again from the features (bit-equal), so the node does not hold on
+        # to them -- with the local-MI node keeping operand planes instead (see _LocalMIHeads) the fp32 tensor dies after the joint forward
+        ctx.recompute = bool(_HEAD_RECOMPUTE and not _GradJoin.enabled and
+                             query("miseg_head_local_bwd_recompute_supported", _DT[feat.dtype], c, s, k))
+        ctx.save_for_backward(feat, w, src, flips, feat.new_empty(0) if ctx.recompute else prob, b)
         ctx.temperature = float(temperature)
         ctx.src_range = getattr(src, "_miseg_range", None)
         return prob
@@ -622,7 +646,7 @@ class _LocalHead(torch.autograd.Function):
         gb = _stacked_grad(ctx.stack_params[1], (s, k), feat.device)
         ws = _ws(query("miseg_head_local_bwd_ws_bytes", m, h, wd, c, s, k), feat.device)
         work = (4.0 * s * k * c * m * h * wd, (3 * s * k * 4.0 + 2 * c * feat.element_size()) * m * h * wd)
-        if compact and _HEAD_RECOMPUTE and query("miseg_head_local_bwd_recompute_supported", _DT[feat.dtype], c, s, k):
+        if ctx.recompute:
             # the kernel computes the probabilities again from the features (bit-equal to the forward's): it reads gprob only
             call("miseg_head_local_bwd_recompute", _stream(), _DT[feat.dtype], _ptr(feat), bsz, h, wd, c, _ptr(src), _ptr(flips), m, _ptr(w),
                  _ptr(b), s, k, ctx.temperature, _ptr(gprob), _ptr(gfeat), n0, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),

@@ -630,6 +630,109 @@ def test_local_head_backward_recomputing_the_probabilities_is_bit_equal(dtype, h
                    b.data_ptr(), s, k, temp, gprob.data_ptr(), gfeat.data_ptr(), 2, gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb)
 
 
+# ------------------------------------------------------------------------------------------ operand planes of the f16 + fp8 backward
+_PLANE_CASES = [(2, 2, 24, 40, [(0, 24, 0, 40)]), (2, 3, 70, 150, [(0, 70, 0, 150)]), (1, 2, 64, 160, [(3, 40, 10, 90), (41, 64, 70, 160)]),
+                (2, 2, 50, 90, [(5, 45, 13, 77)]), (1, 1, 128, 256, [(0, 128, 0, 256)])]
+
+
+def _plane_views(buf, maps, h, w):
+    """(p16, p8l, p8h) as [maps, h, w, bytes-per-pixel] views of a plane buffer (layout: csrc/mi_local.h, 4 KiB of slack around each)."""
+    out, off = [], 4096
+    for bpp in (40, 24, 24):
+        out.append(buf[off:off + maps * h * w * bpp].view(maps, h, w, bpp))
+        off += maps * h * w * bpp + 4096
+    return out
+
+
+@pytest.mark.parametrize("s,ub,h,w,wins", _PLANE_CASES)
+def test_local_mi_operand_planes_forward_by_product_and_backward(s, ub, h, w, wins):
+    """(1) miseg_iic_local_joint_fwd_heads_planes returns the joint of miseg_iic_local_joint_fwd_heads bit for bit and leaves, inside the
+    windows, exactly the planes miseg_iic_local_make_planes writes (f16 hi, e4m3 of the scaled residual and of the scaled value,
+    classes 20..23 zero) -- checked against a torch restatement of the split as well.  (2) miseg_iic_local_bwd_heads_planes on those
+    planes equals miseg_iic_local_bwd_heads at precision f16f8 bit for bit (same operand bytes, same MFMA order), store and
+    accumulate forms, ragged strips, windows inside the image (zero padding at WINDOW edges), rows and columns outside them untouched."""
+    from miseg_amd import _cabi
+    k, pad, t, P = 20, 3, 7, len(wins)
+    torch.manual_seed(7)
+    probs = torch.randn(s, 2 * ub, k, h, w, device=DEV).mul_(2.0).softmax(2).contiguous()
+    win = torch.tensor(wins, dtype=torch.int32, device=DEV).view(P, 4)
+    st = torch.cuda.current_stream().cuda_stream
+    jws = torch.empty(_cabi.query("miseg_iic_local_joint_ws_bytes", ub, k, h, w, pad, P * s), dtype=torch.uint8, device=DEV)
+    pb = _cabi.query("miseg_iic_local_planes_bytes", s, ub, k, h, w, pad)
+    assert pb == s * 2 * ub * h * w * 88 + 4 * 4096
+    assert _cabi.query("miseg_iic_local_planes_bytes", s, ub, k, h, w, 1) == 0 and _cabi.query("miseg_iic_local_planes_bytes", s, ub, 10, h, w, pad) == 0
+    ref = torch.full((pb,), 0x7F, dtype=torch.uint8, device=DEV)         # 0x7F = NaN in e4m3 / f16 halves: gaps show
+    _cabi.call("miseg_iic_local_make_planes", st, probs.data_ptr(), s, ub, k, h, w, pad, ref.data_ptr(), pb)
+    planes = torch.full((pb,), 0x7F, dtype=torch.uint8, device=DEV)
+    raw0 = torch.full((s, P, t, t, k, k), float("nan"), device=DEV)
+    raw1 = torch.full_like(raw0, float("nan"))
+    _cabi.call("miseg_iic_local_joint_fwd_heads", st, probs.data_ptr(), s, ub, k, h, w, pad, win.data_ptr(), P, raw0.data_ptr(), jws.data_ptr(), jws.numel(), 3)
+    _cabi.call("miseg_iic_local_joint_fwd_heads_planes", st, probs.data_ptr(), s, ub, k, h, w, pad, win.data_ptr(), P, raw1.data_ptr(), jws.data_ptr(),
+               jws.numel(), planes.data_ptr(), pb)
+    assert torch.equal(raw0, raw1)
+    inside = torch.zeros(h, w, dtype=torch.bool, device=DEV)
+    for h0, h1, w0, w1 in wins:
+        inside[h0:h1, w0:w1] = True
+    maps = s * 2 * ub
+    for got, want in zip(_plane_views(planes, maps, h, w), _plane_views(ref, maps, h, w)):
+        assert torch.equal(got[:, inside], want[:, inside])
+    # the split itself, restated: hi = f16(v); the 8-bit planes hold e4m3(2^20 (v - hi)) and e4m3(2^8 v)
+    p16, p8l, p8h = _plane_views(ref, maps, h, w)
+    v = probs.view(maps, k, h, w).permute(0, 2, 3, 1).contiguous()
+    hi = v.to(torch.float16)
+    assert torch.equal(p16.view(torch.float16), hi)
+    assert torch.equal(p8l[..., :k].view(torch.float8_e4m3fn).float(), ((v - hi.float()) * 2.0 ** 20).to(torch.float8_e4m3fn).float())
+    assert torch.equal(p8h[..., :k].view(torch.float8_e4m3fn).float(), (v * 256.0).to(torch.float8_e4m3fn).float())
+    assert int(p8l[..., k:].max()) == 0 and int(p8h[..., k:].max()) == 0
+    # backward
+    graw = torch.randn(s, P, t, t, k, k, device=DEV)
+    scale = torch.rand(s, P, device=DEV) + 0.5
+    bws = torch.empty(_cabi.query("miseg_iic_local_bwd_ws_bytes", k, pad, P * s), dtype=torch.uint8, device=DEV)
+    for accumulate in (0, 1):
+        seed = torch.randn_like(probs)
+        outs = []
+        for use_planes in (False, True):
+            gprob = seed.clone()
+            if use_planes:
+                _cabi.call("miseg_iic_local_bwd_heads_planes", st, planes.data_ptr(), pb, s, ub, k, h, w, pad, win.data_ptr(), P, graw.data_ptr(),
+                           scale.data_ptr(), gprob.data_ptr(), accumulate, bws.data_ptr(), bws.numel())
+            else:
+                _cabi.call("miseg_iic_local_bwd_heads", st, probs.data_ptr(), s, ub, k, h, w, pad, win.data_ptr(), P, graw.data_ptr(), scale.data_ptr(),
+                           gprob.data_ptr(), accumulate, 3, bws.data_ptr(), bws.numel())
+            outs.append(gprob)
+        assert torch.equal(outs[0], outs[1])
+        assert torch.equal(outs[1][..., ~inside], seed[..., ~inside])          # nothing outside the windows is written
+        assert not torch.equal(outs[1][..., inside], seed[..., inside])
+    with pytest.raises(_cabi.MisegError):
+        _cabi.call("miseg_iic_local_bwd_heads_planes", st, planes.data_ptr(), pb - 1, s, ub, k, h, w, pad, win.data_ptr(), P, graw.data_ptr(),
+                   scale.data_ptr(), gprob.data_ptr(), 0, bws.data_ptr(), bws.numel())
+
+
+def test_local_mi_heads_node_keeps_planes_and_matches_the_probability_path():
+    """ops.local_mi_heads at f16f8: with the operand planes (default) the node saves the plane buffer instead of probs and its loss and
+    input gradient are those of the path without planes, bit for bit."""
+    o = ops()
+    prev, prev_planes = o.mi_precision_name(), o._MI_PLANES
+    o.set_mi_precision("f16f8")
+    try:
+        torch.manual_seed(3)
+        s, ub, k, h, w, pad = 2, 2, 20, 40, 72, 3
+        base = torch.randn(s, 2 * ub, k, h, w, device=DEV).softmax(2)
+        res = []
+        for planes in (False, True):
+            o._MI_PLANES = planes
+            probs = base.clone().requires_grad_(True)
+            loss = o.local_mi_heads(probs, ub, pad, [(0, h, 0, w)])
+            saved = loss.grad_fn.saved_tensors[0]
+            assert (saved.dtype == torch.uint8) == planes
+            g, = torch.autograd.grad(loss.sum(), probs)
+            res.append((loss.detach().clone(), g))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    finally:
+        o._MI_PLANES = prev_planes
+        o.set_mi_precision(prev)
+
+
 # ------------------------------------------------------------------------------------------ head variants (mlp / normalize)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("head_type,normalize", [("mlp", False), ("mlp", True), ("linear", True)])
