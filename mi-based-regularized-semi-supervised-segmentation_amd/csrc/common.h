@@ -300,18 +300,6 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 // Deterministic sum over `nparts` partial vectors: out[e] = sum_q parts[q*stride + map(e)].
 // 64 outputs x 4 split-groups per 256-thread block; each group sums q = g, g+4, ... serially, the 4 group
 // sums are added in fixed order -> bitwise reproducible, 4x the memory-level parallelism of one thread per output.
-// One reduced vector, two destinations (weight and bias gradients): a kernel, not two hipMemcpyAsync -- a DtoD memcpy on a busy
-// device was seen to take 0.67 ms for 256 bytes (profiles/r01j).
-template <int DUMMY = 0>
-__global__ void split2_kernel(const float* __restrict__ src, int n0, float* __restrict__ d0, int n1, float* __restrict__ d1) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < n0) d0[e] = src[e];
-    else if (e < n0 + n1) d1[e - n0] = src[e];
-}
-static inline void launch_split2(hipStream_t st, const float* src, int n0, float* d0, int n1, float* d1) {
-    hipLaunchKernelGGL(split2_kernel<0>, dim3((unsigned)((n0 + n1 + 255) / 256)), dim3(256), 0, st, src, n0, d0, n1, d1);
-}
-
 // reduce_partials_block: outputs per block depend on the number of parts (host side: reduce_grid)
 constexpr int kWideReduceParts = 64, kFlatReduceParts = 16;
 static inline unsigned reduce_grid(int64_t total, int64_t nparts) {
@@ -321,9 +309,16 @@ static inline unsigned reduce_grid(int64_t total, int64_t nparts) {
 
 // `map(e)`: offset of reduction element e inside one part; `omap(e)`: where its sum goes in `out` (negative: nowhere).  Keep
 // consecutive e contiguous in the PARTS (that is where the bytes are); let the output index take the permutation.
-template <typename MapFn, typename OutFn>
+// `out`: anything indexable that yields a float lvalue -- a float*, or Split2Out below (one reduced vector, two destinations).
+struct Split2Out {          // elements [0, n0) -> d0, the rest -> d1 (stacked weight | bias gradients into their own buffers)
+    float* d0;
+    int n0;
+    float* d1;
+    __device__ __forceinline__ float& operator[](int i) const { return i < n0 ? d0[i] : d1[i - n0]; }
+};
+template <typename OutT, typename MapFn, typename OutFn>
 __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
-                                                      float* __restrict__ out, MapFn map, OutFn omap) {
+                                                      OutT out, MapFn map, OutFn omap) {
     __shared__ float rp_sm[16][64];
     if (nparts <= kFlatReduceParts) {
         // few parts, many outputs: one thread per output, the parts summed in order from registers (no LDS, no barrier)
@@ -382,9 +377,9 @@ __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ 
     }
 }
 
-template <typename MapFn>
+template <typename OutT, typename MapFn>
 __device__ __forceinline__ void reduce_partials_block(const float* __restrict__ parts, int nparts, size_t stride, int total,
-                                                      float* __restrict__ out, MapFn map) {
+                                                      OutT out, MapFn map) {
     reduce_partials_block(parts, nparts, stride, total, out, map, [](int e) { return e; });
 }
 

@@ -1509,8 +1509,9 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
         partials[(size_t)blockIdx.x * (CO * CI + CO) + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
 }
 
-__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ out) {
-    reduce_partials_block(partials, nparts, (size_t)len, len, out, [](int e) { return (size_t)e; });
+__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict__ partials, int nparts, int len, int n0, float* __restrict__ d0,
+                                                         float* __restrict__ d1) {
+    reduce_partials_block(partials, nparts, (size_t)len, len, Split2Out{d0, n0, d1}, [](int e) { return (size_t)e; });
 }
 
 static inline int tile_w(int64_t W) { return W >= 32 ? 32 : 16; }
@@ -1988,10 +1989,8 @@ extern "C" int miseg_conv1x1_bwd(void* stream, int dt, const void* in, const flo
 #undef L
     MISEG_LAUNCH_CHECK("conv1x1_bwd_kernel");
     const int len = (int)(Cout * Cin + Cout);
-    // gw [Cout*Cin] and gbias [Cout] are reduced into one contiguous scratch vector, then split
-    float* red = (float*)ws + (size_t)nb * len;
-    hipLaunchKernelGGL(sum_parts2_kernel, dim3(reduce_grid(len, nb)), dim3(256), 0, st, (const float*)ws, nb, len, red);
+    // the blocks' [gw | gbias] partial vectors, summed straight into the two gradients
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3(reduce_grid(len, nb)), dim3(256), 0, st, (const float*)ws, nb, len, (int)(Cout * Cin), gw, gbias);
     MISEG_LAUNCH_CHECK("sum_parts2_kernel");
-    launch_split2(st, red, (int)(Cout * Cin), gw, (int)Cout, gbias);
     return MISEG_OK;
 }

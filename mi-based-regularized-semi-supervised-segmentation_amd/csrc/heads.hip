@@ -913,8 +913,9 @@ __global__ __launch_bounds__(256, 2) void head_local_bwd_wave_kernel(const bf16*
     }
 }
 
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ out) {
-    reduce_partials_block(partials, nparts, (size_t)len, len, out, [](int e) { return (size_t)e; });
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int nparts, int len, int n0, float* __restrict__ d0,
+                                                           float* __restrict__ d1) {
+    reduce_partials_block(partials, nparts, (size_t)len, len, Split2Out{d0, n0, d1}, [](int e) { return (size_t)e; });
 }
 
 }  // namespace miseg
@@ -1088,9 +1089,8 @@ static int head_local_bwd_impl(void* stream, int dt, const void* feat, int64_t B
 #undef HLB2
     MISEG_LAUNCH_CHECK("head_local_bwd_fused_kernel");
     const int len = R * (int)C + R;
-    float* red = partials + (size_t)nblk * len;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(reduce_grid(len, nused)), dim3(256), 0, st, partials, nused, len, red);
+    // the blocks' [gw | gb] partial vectors, summed straight into the two gradients
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(reduce_grid(len, nused)), dim3(256), 0, st, partials, nused, len, R * (int)C, gw, gb);
     MISEG_LAUNCH_CHECK("sum_partials_kernel");
-    launch_split2(st, red, R * (int)C, gw, R, gb);
     return MISEG_OK;
 }
