@@ -142,7 +142,7 @@ def cpu_baseline(threads):
 PMC_FILE = "r04_pmc.json"
 PMC_KERNEL = {   # bench tag -> kernel name prefix in profiles/r04_pmc.json (the shipped arithmetic: --mi-precision f16f8)
     "iic_local_bwd[p3]": "local_bwd_f8_kernel<20, 3", "iic_local_bwd[p1]": "local_bwd_rows_kernel<20, 1, 3",
-    "iic_local_joint_fwd[p3]": "joint_fwd_px_kernel<3, 3>", "iic_local_joint_fwd[p1]": "joint_fwd_px_kernel<1, 3>",
+    "iic_local_joint_fwd[p3]": "joint_fwd_px_kernel<3, 3", "iic_local_joint_fwd[p1]": "joint_fwd_px_kernel<1, 3",
 }
 
 

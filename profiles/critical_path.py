@@ -7,9 +7,13 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"]) for r in rows)
 adam = [i for i, e in enumerate(ev) if "adam" in e[2]]          # the optimiser kernel ends a step
-seg = ev[adam[-2] + 1:adam[-1] + 1]
+# the step of MEDIAN length among the last six (all replayed from the launch tape in a `--steps 8` run): a single step can carry a
+# host hiccup of the profiled run
+cands = [ev[adam[i - 1] + 1:adam[i] + 1] for i in range(max(1, len(adam) - 6), len(adam))]
+cands.sort(key=lambda g: max(e[1] for e in g) - g[0][0])
+seg = cands[len(cands) // 2]
 t0 = seg[0][0]
-print("Per-stream view of ONE training step (times in us from the step's first kernel; the profiler's tracing slows the host,")
+print("Per-stream view of ONE training step, the median-length one of the run's last six (times in us from the step's first kernel; the profiler's tracing slows the host,")
 print("so host-side gaps are larger than in an unprofiled step).  Made by profiles/critical_path.py from the kernel trace.\n")
 streams = collections.defaultdict(list)
 for s, e, n, st in seg:
