@@ -1163,38 +1163,53 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_wgrad_bf16_kernel(ConvSrc src,
         for (int idx = tid; idx < kBwdCoefRows * 32; idx += kCT) Cf[idx] = co0 + (idx & 31) < Cout ? bl.coef[(size_t)(idx >> 5) * Cout + co0 + (idx & 31)] : 0.f;
         __syncthreads();
     }
+    // A thread's slots of the two operand tiles never change: which pixel of the tile, which 8 channels, which source tensor.  Worked out
+    // once -- per tile only the tile's corner moves (scalar) and two range tests per slot remain.  (Derived per tile, the index math was
+    // ~10 vector instructions per MFMA: profiles/r04_pmc.json, SQ_INSTS_VALU / SQ_INSTS_MFMA of this kernel.)
+    int g_iy[NG], g_ix[NG], g_rel[NG];                    // activation-gradient tile: row, column, element offset from the tile's corner (< 0: no such channel)
+    int i_iy[NI], i_ix[NI], i_rel[NI], i_src[NI];         // input tile with halo: row - 1, column - 1, offset inside its source, source (0 | 1; -1: no slot)
+    {
+        const int hs0 = H >> src.ups0, ws0 = W >> src.ups0, ws1 = W >> src.ups1;
+        (void)hs0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, c = co0 + v * 8;
+            g_ix[j] = px % WG_TW, g_iy[j] = px / WG_TW;
+            g_rel[j] = c < Cout ? (g_iy[j] * W + g_ix[j]) * Cout + c : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, cc = ci0 + v * 8;
+            i_ix[j] = px % IW - 1, i_iy[j] = px / IW - 1;
+            const bool slot = idx < NIPX * (3 + 1) && cc < Cin, first = cc < src.C0;
+            i_src[j] = slot ? (first ? 0 : 1) : -1;
+            // (h0 + d) >> ups = (h0 >> ups) + (d >> ups): tile corners are multiples of 8 x 32, the shift is arithmetic (d = -1 stays outside)
+            i_rel[j] = first ? ((i_iy[j] >> src.ups0) * ws0 + (i_ix[j] >> src.ups0)) * src.C0 + cc
+                             : ((i_iy[j] >> src.ups1) * ws1 + (i_ix[j] >> src.ups1)) * src.C1 + cc - src.C0;
+        }
+    }
     auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
         const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+        const bf16* gcorner = gout + (((size_t)n * H + h0) * W + w0) * Cout;
+        const bf16* ycorner = BNL ? reinterpret_cast<const bf16*>(bl.gy) + (((size_t)n * H + h0) * W + w0) * Cout : nullptr;
+        const bf16* s0 = reinterpret_cast<const bf16*>(src.p0) + (((size_t)n * (H >> src.ups0) + (h0 >> src.ups0)) * (W >> src.ups0) + (w0 >> src.ups0)) * src.C0;
+        const bf16* s1 = reinterpret_cast<const bf16*>(src.p1) + (((size_t)n * (H >> src.ups1) + (h0 >> src.ups1)) * (W >> src.ups1) + (w0 >> src.ups1)) * src.C1;
         okg = 0;
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, ix = px % WG_TW, iy = px / WG_TW;
-            const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
             uint4 val = zero4;
-            if (h < H && w < W && c < Cout) {
-                const size_t o = (((size_t)n * H + h) * W + w) * Cout + c;
-                if (BNL) { pr[j] = *reinterpret_cast<const uint4*>(gout + o); val = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(bl.gy) + o); okg |= 1u << j; }
-                else val = *reinterpret_cast<const uint4*>(gout + o);
+            if (g_rel[j] >= 0 && g_iy[j] < H - h0 && g_ix[j] < W - w0) {
+                if (BNL) { pr[j] = *reinterpret_cast<const uint4*>(gcorner + g_rel[j]); val = *reinterpret_cast<const uint4*>(ycorner + g_rel[j]); okg |= 1u << j; }
+                else val = *reinterpret_cast<const uint4*>(gcorner + g_rel[j]);
             }
             pg[j] = val;
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int idx = tid + kCT * j, v = idx & 3, px = idx >> 2, ix = px % IW, iy = px / IW;
-            const int h = h0 - 1 + iy, w = w0 - 1 + ix, cc = ci0 + v * 8;
             uint4 val = zero4;
-            if (idx < NIPX * 4 && h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
-                const bf16* sp;
-                if (cc < src.C0) {
-                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
-                    sp = reinterpret_cast<const bf16*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + cc;
-                } else {
-                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
-                    sp = reinterpret_cast<const bf16*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + cc - src.C0;
-                }
-                val = *reinterpret_cast<const uint4*>(sp);
-            }
+            if (i_src[j] >= 0 && (unsigned)(h0 + i_iy[j]) < (unsigned)H && (unsigned)(w0 + i_ix[j]) < (unsigned)W)
+                val = *reinterpret_cast<const uint4*>((i_src[j] ? s1 : s0) + i_rel[j]);
             pi[j] = val;
         }
     };
@@ -1303,38 +1318,51 @@ __global__ __launch_bounds__(kCT, BNL ? 3 : 4) void conv3x3_wgrad_bf16_c16_kerne
         for (int idx = tid; idx < kBwdCoefRows * 16; idx += kCT) Cf[idx] = co0 + (idx & 15) < Cout ? bl.coef[(size_t)(idx >> 4) * Cout + co0 + (idx & 15)] : 0.f;
         __syncthreads();
     }
+    // tile-invariant slot geometry, as in conv3x3_wgrad_bf16_kernel
+    int g_iy[NG], g_ix[NG], g_rel[NG];                    // activation-gradient tile: row, column, element offset from the tile's corner (< 0: no such channel)
+    int i_iy[NI], i_ix[NI], i_rel[NI], i_src[NI];         // input tile with halo: row - 1, column - 1, offset inside its source, source (0 | 1; -1: no slot)
+    {
+        const int hs0 = H >> src.ups0, ws0 = W >> src.ups0, ws1 = W >> src.ups1;
+        (void)hs0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, c = co0 + v * 8;
+            g_ix[j] = px % WG_TW, g_iy[j] = px / WG_TW;
+            g_rel[j] = c < Cout ? (g_iy[j] * W + g_ix[j]) * Cout + c : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, cc = ci0 + v * 8;
+            i_ix[j] = px % IW - 1, i_iy[j] = px / IW - 1;
+            const bool slot = idx < NIPX * (1 + 1) && cc < Cin, first = cc < src.C0;
+            i_src[j] = slot ? (first ? 0 : 1) : -1;
+            // (h0 + d) >> ups = (h0 >> ups) + (d >> ups): tile corners are multiples of 8 x 32, the shift is arithmetic (d = -1 stays outside)
+            i_rel[j] = first ? ((i_iy[j] >> src.ups0) * ws0 + (i_ix[j] >> src.ups0)) * src.C0 + cc
+                             : ((i_iy[j] >> src.ups1) * ws1 + (i_ix[j] >> src.ups1)) * src.C1 + cc - src.C0;
+        }
+    }
     auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int tc = tile % tilesC, tr = (tile / tilesC) % tilesR, n = tile / (tilesC * tilesR);
         const int h0 = tr * WG_TH, w0 = tc * WG_TW;
+        const bf16* gcorner = gout + (((size_t)n * H + h0) * W + w0) * Cout;
+        const bf16* ycorner = BNL ? reinterpret_cast<const bf16*>(bl.gy) + (((size_t)n * H + h0) * W + w0) * Cout : nullptr;
+        const bf16* s0 = reinterpret_cast<const bf16*>(src.p0) + (((size_t)n * (H >> src.ups0) + (h0 >> src.ups0)) * (W >> src.ups0) + (w0 >> src.ups0)) * src.C0;
+        const bf16* s1 = reinterpret_cast<const bf16*>(src.p1) + (((size_t)n * (H >> src.ups1) + (h0 >> src.ups1)) * (W >> src.ups1) + (w0 >> src.ups1)) * src.C1;
         okg = 0;
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, ix = px % WG_TW, iy = px / WG_TW;
-            const int h = h0 + iy, w = w0 + ix, c = co0 + v * 8;
             uint4 val = zero4;
-            if (h < H && w < W && c < Cout) {
-                const size_t o = (((size_t)n * H + h) * W + w) * Cout + c;
-                if (BNL) { pr[j] = *reinterpret_cast<const uint4*>(gout + o); val = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(bl.gy) + o); okg |= 1u << j; }
-                else val = *reinterpret_cast<const uint4*>(gout + o);
+            if (g_rel[j] >= 0 && g_iy[j] < H - h0 && g_ix[j] < W - w0) {
+                if (BNL) { pr[j] = *reinterpret_cast<const uint4*>(gcorner + g_rel[j]); val = *reinterpret_cast<const uint4*>(ycorner + g_rel[j]); okg |= 1u << j; }
+                else val = *reinterpret_cast<const uint4*>(gcorner + g_rel[j]);
             }
             pg[j] = val;
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int idx = tid + kCT * j, v = idx & 1, px = idx >> 1, ix = px % IW, iy = px / IW;
-            const int h = h0 - 1 + iy, w = w0 - 1 + ix, cc = ci0 + v * 8;
             uint4 val = zero4;
-            if (idx < NIPX * 2 && h >= 0 && h < H && w >= 0 && w < W && cc < Cin) {
-                const bf16* sp;
-                if (cc < src.C0) {
-                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
-                    sp = reinterpret_cast<const bf16*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + cc;
-                } else {
-                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
-                    sp = reinterpret_cast<const bf16*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + cc - src.C0;
-                }
-                val = *reinterpret_cast<const uint4*>(sp);
-            }
+            if (i_src[j] >= 0 && (unsigned)(h0 + i_iy[j]) < (unsigned)H && (unsigned)(w0 + i_ix[j]) < (unsigned)W)
+                val = *reinterpret_cast<const uint4*>((i_src[j] ? s1 : s0) + i_rel[j]);
             pi[j] = val;
         }
     };
