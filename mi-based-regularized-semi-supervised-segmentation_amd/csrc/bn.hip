@@ -46,15 +46,49 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
     }
 }
 
+// ---- ACC forms of the apply kernels: the batch statistics arrive as the two fixed-point totals per channel the producing convolution
+// accumulated (common.h bn_acc_add); every block works the coefficients out itself (C <= 256 threads, a few double operations each)
+// and keeps them in LDS, block 0 also writes `saved` for the backward and moves the running statistics -- bn_finalize_kernel's
+// formulas with the variance taken in double.
+struct BnAccArgs {
+    const unsigned long long* acc;
+    const float* gamma; const float* beta; float* rmean; float* rvar; long long* nbt; float* saved;
+    float count, eps, momentum;
+};
+constexpr int kBnAccMaxC = 256;
+__device__ __forceinline__ void bn_acc_coeffs(const BnAccArgs& a, int C, float* sc_sh /* LDS [2][kBnAccMaxC] */) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double m = bn_acc_value(a.acc[c]) / (double)a.count, e2 = bn_acc_value(a.acc[C + c]) / (double)a.count;
+        const float mean = (float)m, var = fmaxf((float)(e2 - m * m), 0.f);         // biased batch variance (NaN stays NaN: fmaxf(NaN, 0) = 0 would hide a poisoned sum)
+        const float varn = (m == m && e2 == e2) ? var : __builtin_nanf("");
+        const float invstd = rsqrtf(varn + a.eps), sc = a.gamma[c] * invstd, sh = a.beta[c] - mean * sc;
+        sc_sh[c] = sc;
+        sc_sh[kBnAccMaxC + c] = sh;
+        if (blockIdx.x == 0) {
+            a.saved[c] = mean; a.saved[C + c] = invstd; a.saved[2 * C + c] = sc; a.saved[3 * C + c] = sh;
+            if (a.rmean) {
+                const float unb = a.count > 1.f ? varn * a.count / (a.count - 1.f) : varn;
+                a.rmean[c] = (1.f - a.momentum) * a.rmean[c] + a.momentum * mean;
+                a.rvar[c] = (1.f - a.momentum) * a.rvar[c] + a.momentum * unb;
+                if (c == 0 && a.nbt) a.nbt[0] += 1;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // ---- y = relu(raw*scale+shift); optional 2x2 max-pool of y (one thread = one 2x2 window x V channels)
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ raw, int N, int H, int W, int C,
-                                                          const float* __restrict__ saved, T* __restrict__ y, T* __restrict__ pooled) {
+                                                          const float* __restrict__ saved, T* __restrict__ y, T* __restrict__ pooled,
+                                                          BnAccArgs acc = BnAccArgs{}) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
     const int CV = C / V;
-    const float* scale = saved + 2 * C;
-    const float* shift = saved + 3 * C;
+    __shared__ float cf_lds[ACC ? 2 * kBnAccMaxC : 1];
+    if (ACC) bn_acc_coeffs(acc, C, cf_lds);
+    const float* scale = ACC ? cf_lds : saved + 2 * C;
+    const float* shift = ACC ? cf_lds + kBnAccMaxC : saved + 3 * C;
     if (!POOL) {
         const int64_t total = (int64_t)N * H * W * CV;
         for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -97,14 +131,17 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ 
 // the vertical max itself and the horizontal one from its partner lane L ^ CV; the c = 0 lanes store the pooled vector.  (In
 // bn_relu_fwd_kernel<T, true> a lane owns the whole window: its two loads of a row are CV vectors apart, every load instruction
 // touches half of each cache line it fetches: 4.7 TB/s against the 6.7 of the unpooled kernel.)  Needs 2 CV <= 64 lanes.
-template <typename T>
+template <typename T, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_relu_fwd_pool_kernel(const T* __restrict__ raw, int N, int H, int W, int C,
-                                                               const float* __restrict__ saved, T* __restrict__ y, T* __restrict__ pooled) {
+                                                               const float* __restrict__ saved, T* __restrict__ y, T* __restrict__ pooled,
+                                                               BnAccArgs acc = BnAccArgs{}) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
     const int CV = C / V, Hp = H / 2, Wp = W / 2, RV = W * CV;           // RV: vectors per image row
-    const float* scale = saved + 2 * C;
-    const float* shift = saved + 3 * C;
+    __shared__ float cf_lds[ACC ? 2 * kBnAccMaxC : 1];
+    if (ACC) bn_acc_coeffs(acc, C, cf_lds);
+    const float* scale = ACC ? cf_lds : saved + 2 * C;
+    const float* shift = ACC ? cf_lds + kBnAccMaxC : saved + 3 * C;
     const int64_t total = (int64_t)N * Hp * RV;                           // one lane per (row pair, column pixel, channel vector)
     const int64_t span = ((total + 255) / 256) * 256;                     // whole blocks run the loop: the shuffles need every lane
     for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < span; e += (int64_t)gridDim.x * 256) {
@@ -507,6 +544,41 @@ extern "C" int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t 
         if (pooled) hipLaunchKernelGGL((bn_relu_fwd_kernel<bf16, true>), dim3(nb), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)pooled);
         else hipLaunchKernelGGL((bn_relu_fwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)nullptr);
     } else return fail(MISEG_E_INVALID, "bn_relu_fwd: bad dtype");
+    MISEG_LAUNCH_CHECK("bn_relu_fwd_kernel");
+    return MISEG_OK;
+}
+
+// miseg_bn_finalize + miseg_bn_relu_fwd in one launch, the statistics read from the accumulator miseg_conv3x3_fwd_acc filled
+extern "C" int miseg_bn_relu_fwd_acc(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C, const void* acc,
+                                     const float* gamma, const float* beta, float eps, float momentum, float* rmean, float* rvar, int64_t* nbt,
+                                     float* saved, void* y, void* pooled) {
+    MISEG_TAPE(miseg_bn_relu_fwd_acc, stream, dt, raw, N, H, W, C, acc, gamma, beta, eps, momentum, rmean, rvar, nbt, saved, y, pooled);
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_fwd_acc, stream, MISEG_BF16, raw, N, H, W, C, acc, gamma, beta, eps, momentum, rmean, rvar, nbt, saved, y, pooled);
+    MISEG_REQUIRE(raw && acc && gamma && beta && saved && y, "bn_relu_fwd_acc: null pointer");
+    const int V = dt == MISEG_BF16 ? 8 : 4;
+    MISEG_REQUIRE(C % V == 0 && C <= kBnAccMaxC, "bn_relu_fwd_acc: C must be a multiple of %d and <= %d", V, kBnAccMaxC);
+    MISEG_REQUIRE(!pooled || (H % 2 == 0 && W % 2 == 0), "bn_relu_fwd_acc: pooling needs even H, W");
+    MISEG_REQUIRE((rmean == nullptr) == (rvar == nullptr), "bn_relu_fwd_acc: running mean and variance come together");
+    hipStream_t st = as_stream(stream);
+    const BnAccArgs a{static_cast<const unsigned long long*>(acc), gamma, beta, rmean, rvar, (long long*)nbt, saved, (float)(N * H * W), eps, momentum};
+    const int64_t total = pooled ? N * (H / 2) * (W / 2) * (C / V) : N * H * W * (C / V);
+    const int nb = ew_blocks(total);
+    const int CV = (int)(C / V);
+    if (pooled && CV <= 32 && (CV & (CV - 1)) == 0) {
+        const int nbp = ew_blocks(N * (H / 2) * W * CV);
+        if (dt == MISEG_F32) hipLaunchKernelGGL((bn_relu_fwd_pool_kernel<float, true>), dim3(nbp), dim3(256), 0, st, (const float*)raw, (int)N, (int)H, (int)W, (int)C, saved, (float*)y, (float*)pooled, a);
+        else if (dt == MISEG_BF16) hipLaunchKernelGGL((bn_relu_fwd_pool_kernel<bf16, true>), dim3(nbp), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)pooled, a);
+        else return fail(MISEG_E_INVALID, "bn_relu_fwd_acc: bad dtype");
+        MISEG_LAUNCH_CHECK("bn_relu_fwd_pool_kernel");
+        return MISEG_OK;
+    }
+    if (dt == MISEG_F32) {
+        if (pooled) hipLaunchKernelGGL((bn_relu_fwd_kernel<float, true, true>), dim3(nb), dim3(256), 0, st, (const float*)raw, (int)N, (int)H, (int)W, (int)C, saved, (float*)y, (float*)pooled, a);
+        else hipLaunchKernelGGL((bn_relu_fwd_kernel<float, false, true>), dim3(nb), dim3(256), 0, st, (const float*)raw, (int)N, (int)H, (int)W, (int)C, saved, (float*)y, (float*)nullptr, a);
+    } else if (dt == MISEG_BF16) {
+        if (pooled) hipLaunchKernelGGL((bn_relu_fwd_kernel<bf16, true, true>), dim3(nb), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)pooled, a);
+        else hipLaunchKernelGGL((bn_relu_fwd_kernel<bf16, false, true>), dim3(nb), dim3(256), 0, st, (const bf16*)raw, (int)N, (int)H, (int)W, (int)C, saved, (bf16*)y, (bf16*)nullptr, a);
+    } else return fail(MISEG_E_INVALID, "bn_relu_fwd_acc: bad dtype");
     MISEG_LAUNCH_CHECK("bn_relu_fwd_kernel");
     return MISEG_OK;
 }

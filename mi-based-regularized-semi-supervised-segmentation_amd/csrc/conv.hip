@@ -326,8 +326,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvSrc src, int N,
 #pragma unroll
             for (int q = 4; q < NW; ++q) { a += sred[q][0][tid]; b += sred[q][1][tid]; }
             if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
-            store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
-            store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
+            if (!RED && fin.acc) {
+                bn_acc_add(fin.acc + co0 + tid, a);
+                bn_acc_add(fin.acc + Cout + co0 + tid, b);
+            } else {
+                store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
+                store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
+            }
         }
         if (!RED && fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {   // the tile memory is dead: scratch for the sums
             bn_finish_block(stats, (int)gridDim.x, Cout, fin, reinterpret_cast<float*>(smem));
@@ -556,8 +561,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int
             float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
 #pragma unroll
             for (int q = 4; q < NW; ++q) { a += sred[q][0][tid]; b += sred[q][1][tid]; }
-            stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
-            stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
+            if (fin.acc) {
+                bn_acc_add(fin.acc + co0 + tid, a);
+                bn_acc_add(fin.acc + Cout + co0 + tid, b);
+            } else {
+                stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
+                stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
+            }
         }
     }
 }
@@ -929,8 +939,14 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
         if (tid < COT && co0 + tid < Cout) {
             float b = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
             if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
-            store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid]);
-            store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
+            const float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
+            if (!RED && fin.acc) {
+                bn_acc_add(fin.acc + co0 + tid, a);
+                bn_acc_add(fin.acc + Cout + co0 + tid, b);
+            } else {
+                store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
+                store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
+            }
         }
         if (!RED && fin.counter && last_block_arrives(fin.counter, gridDim.x * gridDim.y)) {
             bn_finish_block(stats, (int)gridDim.x, Cout, fin, reinterpret_cast<float*>(smem));
@@ -1870,6 +1886,18 @@ extern "C" int miseg_conv3x3_dgrad_bn(void* stream, int dt, const void* raw_or_g
 
 // The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.
 static const int64_t kBnFinishMaxFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
+
+// miseg_conv3x3_fwd with the BatchNorm statistics added into acc[2 Cout] (fixed point, common.h bn_acc_add) instead of written as one row
+// per block: no finalize launch -- miseg_bn_relu_fwd_acc reads the two totals of a channel itself
+extern "C" int miseg_conv3x3_fwd_acc(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
+                                     int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, void* acc) {
+    MISEG_TAPE(miseg_conv3x3_fwd_acc, stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, acc);
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_acc, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, acc);
+    MISEG_REQUIRE(acc && ((uintptr_t)acc & 7) == 0, "conv3x3_fwd_acc: the accumulator must be an 8-byte aligned [2 Cout] array");
+    BnFinish fin{};
+    fin.acc = static_cast<unsigned long long*>(acc);
+    return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, reinterpret_cast<float*>(acc), fin);
+}
 
 extern "C" int64_t miseg_conv3x3_bn_fwd_fusable(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
     const int64_t parts = miseg_conv3x3_stats_parts(dt == MISEG_F16 ? MISEG_BF16 : dt, Cin, N, H, W);

@@ -24,8 +24,9 @@ from ._cabi import call
 FLIPS_OFF, FLIPS_CAP = 0, 512                 # int32
 HYPER_OFF, HYPER_CAP = 2048, 64               # float32: 8 per parameter group (lr/bc1, 1/sqrt(bc2), eps, wd, 1/loss scale)
 COUNT_OFF, COUNT_CAP = 2304, 64               # int32, zero on the host: the upload zeroes the counters
-SEED_OFF, PARAM_BYTES = 2560, 32768
-SEED_CAP = (PARAM_BYTES - SEED_OFF) // 4
+SEED_OFF, ACC_OFF, PARAM_BYTES = 2560, 32768, 65536
+SEED_CAP = (ACC_OFF - SEED_OFF) // 4
+ACC_CAP = (PARAM_BYTES - ACC_OFF) // 8        # int64, zero on the host: the BatchNorm statistics accumulators (miseg_conv3x3_fwd_acc)
 ARENA_FLOATS = 8192
 OUT_BYTES = 65536
 
@@ -64,11 +65,12 @@ class StepIO:
         self._n_flips = 0
         self._groups = 0
         self.scale = 1.0
-        self._cursor_counter = self._cursor_arena = self._cursor_out = 0
+        self._cursor_counter = self._cursor_arena = self._cursor_out = self._cursor_acc = 0
         self._fields: List[Tuple[str, int, int, torch.dtype, tuple]] = []
         # typed views of the device block
         self._d_i32 = self.dev.view(torch.int32)
         self._d_f32 = self.dev.view(torch.float32)
+        self._d_i64 = self.dev.view(torch.int64)
 
     def __del__(self):
         try:
@@ -100,7 +102,7 @@ class StepIO:
             hf[HYPER_OFF // 4 + 8 * gi:HYPER_OFF // 4 + 8 * gi + 5] = torch.tensor(vals, dtype=torch.float32)
         for (numel, coeff), (off, _) in self._seeds.items():
             hf[SEED_OFF // 4 + off:SEED_OFF // 4 + off + numel] = coeff * float(scale)
-        self._cursor_counter = self._cursor_arena = self._cursor_out = 0
+        self._cursor_counter = self._cursor_arena = self._cursor_out = self._cursor_acc = 0
         self._fields = []
         self.last_report = None
         return slot
@@ -130,6 +132,15 @@ class StepIO:
             raise _cabi.MisegError("StepIO: out of assertion counters")
         self._cursor_counter += 1
         return self._d_i32[COUNT_OFF // 4 + i]
+
+    def acc64(self, n: int) -> Optional[Tensor]:
+        """``n`` int64 device words that are zero at the start of the iteration (the upload wrote them): a fixed-point statistics
+        accumulator of one BatchNorm layer.  None when the block has no room left (the caller zero-fills a tensor of its own)."""
+        i = self._cursor_acc
+        if i + n > ACC_CAP:
+            return None
+        self._cursor_acc += n
+        return self._d_i64[ACC_OFF // 8 + i:ACC_OFF // 8 + i + n]
 
     def counters_base(self) -> Tensor:
         return self._d_i32[COUNT_OFF // 4:COUNT_OFF // 4 + COUNT_CAP]

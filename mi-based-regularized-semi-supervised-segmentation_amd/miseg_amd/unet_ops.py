@@ -21,6 +21,7 @@ from ._cabi import call, query
 from .gradslot import grad_slot
 from .ops import _DT, _need_gpu, _ptr, _stream, _ws, as_nhwc, empty_nhwc, wait_stream
 from .tape import keep
+from . import stepio
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
@@ -62,6 +63,9 @@ _FUSE_BN_BWD = os.environ.get("MISEG_BN_FUSE", "0") == "1"
 _FUSE_BN_RED = True      # ... including the statistics pass in the producing data-gradient kernel's epilogue
 # The statistics pass ALONE in the producing data-gradient kernel's epilogue (no loader transform): MISEG_BN_RED=1 (round-4 experiment)
 _RED_ONLY = os.environ.get("MISEG_BN_RED", "0") == "1" and not _FUSE_BN_BWD
+# 1 (default): the forward statistics leave the convolution as fixed-point atomic adds and the apply kernel finishes them itself
+# (miseg_conv3x3_fwd_acc / miseg_bn_relu_fwd_acc): 22 launches fewer per step.  0: one partial row per block + miseg_bn_finalize.
+_BN_ACC = os.environ.get("MISEG_BN_ACC", "1") != "0"
 
 
 class _BnRec:
@@ -288,7 +292,14 @@ class _ConvBNReLU(torch.autograd.Function):
         raw = empty_nhwc(n, cout, h, w, dtype, dev)
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         counter = SYNC_COUNTERS.take(dev) if training and query("miseg_conv3x3_bn_fwd_fusable", _DT[dtype], c0 + c1, n, h, w, cout) else None
-        if training:       # rows of the statistics matrix: one per block of the kernel that will serve this shape
+        acc = None
+        if training and counter is None and _BN_ACC and cout <= 256:
+            # the statistics leave the convolution as fixed-point atomic adds into one [2 C] accumulator that the step block's upload
+            # zeroed; the apply kernel turns them into coefficients itself: no partial rows, no finalize launch
+            io = stepio.current()
+            # (inside an iteration whose block has no room left: the row-per-block path below; stand-alone use of the layer: a zero fill)
+            acc = io.acc64(2 * cout) if io is not None else torch.zeros(2 * cout, dtype=torch.int64, device=dev)
+        if training and acc is None:       # rows of the statistics matrix: one per block of the kernel that will serve this shape
             parts = query("miseg_conv3x3_stats_parts", _DT[dtype], c0 + c1, n, h, w) if counter is not None else \
                 query("miseg_conv3x3_fwd_parts", _DT[dtype], c0 + c1, n, h, w, cout)
             stats = torch.empty(parts * 2 * cout, dtype=torch.float32, device=dev)
@@ -296,22 +307,30 @@ class _ConvBNReLU(torch.autograd.Function):
             parts, stats = 0, None
         es = x0.element_size()
         work = (18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout))
-        if counter is not None:     # the conv's last block turns the partial sums into `saved` / the running statistics itself
+        if acc is not None:
+            call("miseg_conv3x3_fwd_acc", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
+                 _ptr(acc), work=work, tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
+        elif counter is not None:     # the conv's last block turns the partial sums into `saved` / the running statistics itself
             call("miseg_conv3x3_bn_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
                  _ptr(stats), _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved),
                  _ptr(counter), work=work, tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
         else:
             call("miseg_conv3x3_fwd", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
                  _ptr(stats), work=work, tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
-        if training and counter is None:
+        if training and counter is None and acc is None:
             call("miseg_bn_finalize", _stream(), _ptr(stats), parts, cout, n * h * w, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved))
         elif not training:
             call("miseg_bn_eval_coeffs", _stream(), cout, _ptr(gamma), _ptr(beta), BN_EPS, _ptr(running_mean), _ptr(running_var), _ptr(saved))
         y = empty_nhwc(n, cout, h, w, dtype, dev)
         pooled = empty_nhwc(n, cout, h // 2, w // 2, dtype, dev) if want_pool else None
-        call("miseg_bn_relu_fwd", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(saved), _ptr(y), _ptr(pooled),
-             work=(0.0, float(es) * n * h * w * cout * (2.25 if want_pool else 2.0)), tag=f"bn_relu_fwd[{h}x{w},{cout}]")
+        if acc is not None:
+            call("miseg_bn_relu_fwd_acc", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(acc), _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM,
+                 _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(saved), _ptr(y), _ptr(pooled),
+                 work=(0.0, float(es) * n * h * w * cout * (2.25 if want_pool else 2.0)), tag=f"bn_relu_fwd[{h}x{w},{cout}]")
+        else:
+            call("miseg_bn_relu_fwd", _stream(), _DT[dtype], _ptr(raw), n, h, w, cout, _ptr(saved), _ptr(y), _ptr(pooled),
+                 work=(0.0, float(es) * n * h * w * cout * (2.25 if want_pool else 2.0)), tag=f"bn_relu_fwd[{h}x{w},{cout}]")
         ctx.save_for_backward(x0, x1, weight, gamma, raw, y, saved)
         ctx.param_refs = (weight, gamma, beta)   # the Parameter objects (flat-gradient slots hang off them)
         ctx.cfg = (training, ups0, ups1, want_pool, c0, c1, n, h, w, cout)

@@ -267,6 +267,58 @@ def test_bn_statistics_finished_by_the_last_block_equal_the_separate_finalize(sh
         assert all(int(p.abs().sum()) == 0 for p in unet_ops.SYNC_COUNTERS._pool.values())      # every counter is back at zero
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(4, 256, 256, 16, 16), (16, 128, 128, 32, 32), (48, 16, 16, 256, 256), (6, 50, 46, 24, 32), (48, 64, 64, 64, 64),
+                                   (8, 32, 32, 128, 128)])
+def test_bn_statistics_as_fixed_point_accumulators_equal_the_finalize_launch(shape, dtype, monkeypatch):
+    """miseg_conv3x3_fwd_acc + miseg_bn_relu_fwd_acc (the shipped training path: every block of the convolution adds its channel sums to
+    one int64 accumulator, the apply kernel finishes the statistics in its prologue) against miseg_conv3x3_fwd + miseg_bn_finalize +
+    miseg_bn_relu_fwd: same per-block sums, exacter total -> 2e-6 relative on every statistic and gradient (16-bit outputs: one ulp);
+    streaming, persistent tiled and per-tile kernels, pooled and unpooled apply kernels.  Two runs of the accumulator path are
+    IDENTICAL bit for bit (integer adds do not care about the order the blocks arrive in)."""
+    from miseg_amd import unet_ops
+    n, h, w, cin, cout = shape
+    x = nhwc(T(synth.normal(f"bnacc/{shape}/x", (n, cin, h, w))).to(DEV).to(dtype))
+    wt = T(synth.normal(f"bnacc/{shape}/w", (cout, cin, 3, 3), scale=(2.0 / (cin * 9)) ** 0.5)).to(DEV)
+    pool = h % 2 == 0 and w % 2 == 0
+    cot = T(synth.normal(f"bnacc/{shape}/cot", (n, cout, h, w))).to(DEV)
+    monkeypatch.setattr(unet_ops.SYNC_COUNTERS, "enabled", False)
+
+    def run(acc):
+        monkeypatch.setattr(unet_ops, "_BN_ACC", acc)
+        bn = {k: v.to(DEV) for k, v in make_bn(cout, f"bnacc/{shape}/bn").items()}
+        xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        gd, bd = bn["weight"].clone().requires_grad_(True), bn["bias"].clone().requires_grad_(True)
+        y, yp = unet_ops.conv_bn_relu(xd, None, wd, gd, bd, bn["running_mean"], bn["running_var"], bn["nbt"], True, 0, 0, pool)
+        loss = (y.float() * cot).sum() + (yp.float().sum() if pool else 0.0)
+        loss.backward()
+        outs = [y] + ([yp] if pool else []) + [bn["running_mean"], bn["running_var"], gd.grad, bd.grad, xd.grad, wd.grad]
+        return [t.detach().float().cpu() for t in outs] + [int(bn["nbt"])]
+
+    ref, got, again = run(False), run(True), run(True)
+    names = ["y"] + (["pooled"] if pool else []) + ["running_mean", "running_var", "ggamma", "gbeta", "gx", "gw"]
+    assert got[-1] == ref[-1] == 1
+    for a, b, c, name in zip(got[:-1], ref[:-1], again[:-1], names):
+        assert torch.equal(a, c), name
+        tol = 2e-6 if dtype == torch.float32 or name.startswith(("running", "gg", "gb")) else 1.6e-2
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+        assert err <= tol, (name, err)
+
+
+def test_bn_statistics_accumulator_poisoned_by_a_non_finite_activation():
+    """A non-finite (or absurdly large) block sum must not turn into a plausible statistic: the accumulator is poisoned and the batch
+    statistics come out NaN, as with the float path (the kernels' ReLU is fmaxf(v, 0): the activations themselves read 0 either way)."""
+    from miseg_amd import unet_ops
+    n, h, w, c = 2, 16, 32, 16
+    x = nhwc(torch.randn(n, c, h, w, device=DEV).to(torch.bfloat16))
+    x[0, 3, 5, 7] = float("inf")
+    wt = (torch.randn(c, c, 3, 3, device=DEV) * 0.1)
+    bn = {k: v.to(DEV) for k, v in make_bn(c, "bnacc/poison").items()}
+    assert unet_ops._BN_ACC
+    y, _ = unet_ops.conv_bn_relu(x, None, wt, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"], bn["nbt"], True, 0, 0, False)
+    assert not bool(torch.isfinite(bn["running_var"]).all()) and not bool(torch.isfinite(bn["running_mean"]).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(4, 256, 256, 32, 16), (16, 128, 128, 32, 32), (6, 250, 230, 16, 32),
                                    (8, 64, 64, 128, 64), (8, 32, 32, 256, 128), (3, 20, 36, 64, 64)])     # the last three: tiled kernel, 64-channel slices
