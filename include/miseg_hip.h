@@ -432,11 +432,13 @@ int miseg_bn_eval_coeffs(void* stream, int64_t C, const float* gamma, const floa
 int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C,
                       const float* saved, void* y, void* pooled);
 /* BatchNorm batch statistics without a finalize launch (training mode, ref contrastyou/arch/unet.py:14-21: Conv2d -> BatchNorm2d -> ReLU).
- * miseg_conv3x3_fwd_acc = miseg_conv3x3_fwd whose blocks ADD their per-channel sum and sum of squares into acc -- uint64[2 Cout], 8-byte
+ * miseg_conv3x3_fwd_acc = miseg_conv3x3_fwd whose blocks ADD their per-channel sum and sum of squares into acc -- uint64[2 Cout + 1], 8-byte
  * aligned, ZERO before the launch -- as 2^-20 fixed point (integer adds: the totals do not depend on the arrival order, so results stay
- * bit-reproducible; |block sum| < 2^42, beyond that or non-finite the statistics come out NaN).  miseg_bn_relu_fwd_acc =
+ * bit-reproducible; a block sum of 2^30 or more, or a non-finite one, is counted in acc[2 Cout] and the layer's statistics then come out
+ * NaN).  Shapes: miseg_conv3x3_fwd_acc_supported (Cout <= 256, at most 2 048 blocks: the no-wrap bound).  miseg_bn_relu_fwd_acc =
  * miseg_bn_finalize + miseg_bn_relu_fwd: every block turns the totals into scale / shift itself, block 0 writes `saved`
  * ([mean | invstd | scale | shift], what the backward reads) and moves running_mean / running_var / num_batches_tracked.  C <= 256. */
+int64_t miseg_conv3x3_fwd_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout);
 int miseg_conv3x3_fwd_acc(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                           int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, void* acc);
 int miseg_bn_relu_fwd_acc(void* stream, int dt, const void* raw, int64_t N, int64_t H, int64_t W, int64_t C, const void* acc,

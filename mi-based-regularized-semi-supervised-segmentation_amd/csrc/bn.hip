@@ -58,7 +58,8 @@ struct BnAccArgs {
 constexpr int kBnAccMaxC = 256;
 __device__ __forceinline__ void bn_acc_coeffs(const BnAccArgs& a, int C, float* sc_sh /* LDS [2][kBnAccMaxC] */) {
     for (int c = threadIdx.x; c < C; c += 256) {
-        const double m = bn_acc_value(a.acc[c]) / (double)a.count, e2 = bn_acc_value(a.acc[C + c]) / (double)a.count;
+        const unsigned long long misfit = a.acc[2 * C];
+        const double m = bn_acc_value(a.acc[c], misfit) / (double)a.count, e2 = bn_acc_value(a.acc[C + c], misfit) / (double)a.count;
         const float mean = (float)m, var = fmaxf((float)(e2 - m * m), 0.f);         // biased batch variance (NaN stays NaN: fmaxf(NaN, 0) = 0 would hide a poisoned sum)
         const float varn = (m == m && e2 == e2) ? var : __builtin_nanf("");
         const float invstd = rsqrtf(varn + a.eps), sc = a.gamma[c] * invstd, sh = a.beta[c] - mean * sc;

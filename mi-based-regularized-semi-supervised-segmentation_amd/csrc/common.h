@@ -265,24 +265,25 @@ struct BnFinish {
     int accumulate_out;              // POOL epilogues of the conv kernels: add to the output tensor instead of storing (a gradient join)
     void* out1; int split;           // full-resolution epilogues: output channels [split, Cout) go to out1 ([.., Cout - split]), [0, split) to
                                      // out ([.., split]) -- the data gradient of a concat convolution, one launch for both sources
-    unsigned long long* acc;         // non-null: the statistics leave as fixed-point atomic adds into acc[2 Cout] (bn_acc_add) instead of a row per block
+    unsigned long long* acc;         // non-null: the statistics leave as fixed-point atomic adds into acc[2 Cout + 1] (bn_acc_add) instead of a row per block
 };
 
 // ---- BatchNorm batch statistics without a finalize launch.  Every block of the producing convolution adds its per-channel sum and sum of
-// squares to ONE [2 C] accumulator as 64-bit fixed point (2^-20 units): integer addition is associative, so the totals do not depend on
-// the order the blocks arrive in (a float atomic would) -- the step stays bit-reproducible, and the totals are exacter than a float tree
+// squares to ONE accumulator as 64-bit fixed point (2^-20 units): integer addition is associative, so the totals do not depend on the
+// order the blocks arrive in (a float atomic would) -- the step stays bit-reproducible, and the totals are exacter than a float tree
 // (each block rounds once, to 1e-6 absolute).  The consumer (bn_relu_fwd with ACC) turns the two integers of a channel into mean /
 // variance in its prologue; the accumulator is zero at the start of an iteration (the step block's upload, StepIO.acc64).
-// Range: |block sum| < 2^42 (4.4e12) per block and 2^62 in total -- a sum of squares of 3 M activations of magnitude 1 000; anything
-// beyond (or non-finite) poisons the accumulator with 2^62 and the consumer reports NaN statistics, as the float path would.
+// Layout: acc[0 .. 2C) the sums, acc[2C] a count of contributions that did not fit.  Range: |block sum| < 2^30 (1.07e9: the squares of
+// 6 000 activations of magnitude 400), at most 2^11 blocks -> |total| < 2^61, no wrap; a larger or non-finite block sum is counted in
+// acc[2C] instead and the consumer then reports NaN statistics for the layer, as the float path would for a non-finite sum.
 constexpr float kBnAccScale = 1048576.f;
-__device__ __forceinline__ void bn_acc_add(unsigned long long* acc, float v) {
-    const long long q = fabsf(v) < 4.398e12f ? __float2ll_rn(v * kBnAccScale) : (1LL << 62);
-    __hip_atomic_fetch_add(acc, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+constexpr int kBnAccMaxBlocks = 2048;
+__device__ __forceinline__ void bn_acc_add(unsigned long long* acc, unsigned long long* misfit, float v) {
+    if (fabsf(v) < 1.0737e9f) __hip_atomic_fetch_add(acc, (unsigned long long)__float2ll_rn(v * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(misfit, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double bn_acc_value(unsigned long long raw) {
-    const long long q = (long long)raw;
-    return (q >= (1LL << 61) || q <= -(1LL << 61)) ? __builtin_nan("") : (double)q * (1.0 / (double)kBnAccScale);
+__device__ __forceinline__ double bn_acc_value(unsigned long long raw, unsigned long long misfit) {
+    return misfit ? __builtin_nan("") : (double)(long long)raw * (1.0 / (double)kBnAccScale);
 }
 __device__ __forceinline__ void bn_finish_block(const float* __restrict__ parts, int nparts, int C, const BnFinish& f, float* lds) {
     const float* sums = block_column_sums(parts, nparts, 2 * C, lds);      // [sum | sum of squares] per channel

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvSrc src, int N,
             for (int q = 4; q < NW; ++q) { a += sred[q][0][tid]; b += sred[q][1][tid]; }
             if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
             if (!RED && fin.acc) {
-                bn_acc_add(fin.acc + co0 + tid, a);
-                bn_acc_add(fin.acc + Cout + co0 + tid, b);
+                bn_acc_add(fin.acc + co0 + tid, fin.acc + 2 * Cout, a);
+                bn_acc_add(fin.acc + Cout + co0 + tid, fin.acc + 2 * Cout, b);
             } else {
                 store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
                 store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
@@ -562,8 +562,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int
 #pragma unroll
             for (int q = 4; q < NW; ++q) { a += sred[q][0][tid]; b += sred[q][1][tid]; }
             if (fin.acc) {
-                bn_acc_add(fin.acc + co0 + tid, a);
-                bn_acc_add(fin.acc + Cout + co0 + tid, b);
+                bn_acc_add(fin.acc + co0 + tid, fin.acc + 2 * Cout, a);
+                bn_acc_add(fin.acc + Cout + co0 + tid, fin.acc + 2 * Cout, b);
             } else {
                 stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid] = a;
                 stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid] = b;
@@ -941,8 +941,8 @@ __global__ __launch_bounds__(kCT, 2) void conv3x3_stream_kernel(ConvSrc src, int
             if (RED) b *= br.saved[Cout + co0 + tid];          // sum dz * (raw - mean) -> sum dz * xhat
             const float a = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
             if (!RED && fin.acc) {
-                bn_acc_add(fin.acc + co0 + tid, a);
-                bn_acc_add(fin.acc + Cout + co0 + tid, b);
+                bn_acc_add(fin.acc + co0 + tid, fin.acc + 2 * Cout, a);
+                bn_acc_add(fin.acc + Cout + co0 + tid, fin.acc + 2 * Cout, b);
             } else {
                 store_part(&stats[((size_t)blockIdx.x * 2 + 0) * Cout + co0 + tid], a);
                 store_part(&stats[((size_t)blockIdx.x * 2 + 1) * Cout + co0 + tid], b);
@@ -1887,13 +1887,18 @@ extern "C" int miseg_conv3x3_dgrad_bn(void* stream, int dt, const void* raw_or_g
 // The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.
 static const int64_t kBnFinishMaxFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
 
-// miseg_conv3x3_fwd with the BatchNorm statistics added into acc[2 Cout] (fixed point, common.h bn_acc_add) instead of written as one row
+extern "C" int64_t miseg_conv3x3_fwd_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
+    return Cout <= 256 && miseg_conv3x3_fwd_parts(dt, Cin, N, H, W, Cout) <= kBnAccMaxBlocks;       // the fixed point's no-wrap bound
+}
+
+// miseg_conv3x3_fwd with the BatchNorm statistics added into acc[2 Cout + 1] (fixed point, common.h bn_acc_add) instead of written as one row
 // per block: no finalize launch -- miseg_bn_relu_fwd_acc reads the two totals of a channel itself
 extern "C" int miseg_conv3x3_fwd_acc(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                                      int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, void* acc) {
     MISEG_TAPE(miseg_conv3x3_fwd_acc, stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, acc);
     MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_fwd_acc, stream, MISEG_BF16, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, acc);
-    MISEG_REQUIRE(acc && ((uintptr_t)acc & 7) == 0, "conv3x3_fwd_acc: the accumulator must be an 8-byte aligned [2 Cout] array");
+    MISEG_REQUIRE(acc && ((uintptr_t)acc & 7) == 0, "conv3x3_fwd_acc: the accumulator must be an 8-byte aligned [2 Cout + 1] array");
+    MISEG_REQUIRE(miseg_conv3x3_fwd_acc_supported(dt, C0 + C1, N, H, W, Cout), "conv3x3_fwd_acc: shape not supported (ask miseg_conv3x3_fwd_acc_supported)");
     BnFinish fin{};
     fin.acc = static_cast<unsigned long long*>(acc);
     return conv3x3_fwd_impl(stream, dt, in0, C0, ups0, in1, C1, ups1, N, H, W, packed_w, Cout, out, reinterpret_cast<float*>(acc), fin);

@@ -293,12 +293,12 @@ class _ConvBNReLU(torch.autograd.Function):
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         counter = SYNC_COUNTERS.take(dev) if training and query("miseg_conv3x3_bn_fwd_fusable", _DT[dtype], c0 + c1, n, h, w, cout) else None
         acc = None
-        if training and counter is None and _BN_ACC and cout <= 256:
+        if training and counter is None and _BN_ACC and query("miseg_conv3x3_fwd_acc_supported", _DT[dtype], c0 + c1, n, h, w, cout):
             # the statistics leave the convolution as fixed-point atomic adds into one [2 C] accumulator that the step block's upload
             # zeroed; the apply kernel turns them into coefficients itself: no partial rows, no finalize launch
             io = stepio.current()
             # (inside an iteration whose block has no room left: the row-per-block path below; stand-alone use of the layer: a zero fill)
-            acc = io.acc64(2 * cout) if io is not None else torch.zeros(2 * cout, dtype=torch.int64, device=dev)
+            acc = io.acc64(2 * cout + 2) if io is not None else torch.zeros(2 * cout + 2, dtype=torch.int64, device=dev)   # sums + misfit count
         if training and acc is None:       # rows of the statistics matrix: one per block of the kernel that will serve this shape
             parts = query("miseg_conv3x3_stats_parts", _DT[dtype], c0 + c1, n, h, w) if counter is not None else \
                 query("miseg_conv3x3_fwd_parts", _DT[dtype], c0 + c1, n, h, w, cout)
