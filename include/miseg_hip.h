@@ -461,6 +461,14 @@ int miseg_bn_relu_bwd_dual(void* stream, int dt, const void* raw, const void* gy
                            int64_t n2_begin, int64_t n2_end, int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma,
                            const float* saved, int training, void* graw, float* ggamma, float* gbeta, void* ws,
                            int64_t ws_bytes);
+/* The same without a finalize launch: the reduce kernel's blocks add their two sums per channel into acc -- uint64[4 C + 2], 8-byte aligned,
+ * ZERO before the launch; two fixed-point tiers (2^-40 units for gradients as they come, 2^-12 for loss-scaled ones) and a misfit count
+ * per tier -- and the apply kernel takes the finest tier every block fitted.  Integer adds: order-independent, bit-reproducible.
+ * Shapes: miseg_bn_relu_bwd_acc_supported (C <= 256, at most 2 048 reduce blocks). */
+int64_t miseg_bn_relu_bwd_acc_supported(int dt, int64_t N, int64_t H, int64_t W, int64_t C);
+int miseg_bn_relu_bwd_dual_acc(void* stream, int dt, const void* raw, const void* gy, const void* gpool, const void* gy2, int64_t n2_begin,
+                               int64_t n2_end, int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
+                               int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes, void* acc);
 /* bn_relu_bwd WITHOUT its reduce pass: the per-block sums of dz and dz * xhat come from the epilogue of the convolution that wrote gy
  * (miseg_conv3x3_dgrad_bn called with red_raw / red_saved / red_parts and a plain graw input): finalize from ext_parts
  * [ext_nparts][2][C], then the apply pass.  Layers without the fused pool; ws >= 3 C floats. */

@@ -288,6 +288,7 @@ struct BnBwdFinish {
     const float* gamma; float* coeffs; float* ggamma; float* gbeta;
     float count; int training;
     float* bwd_coef;                 // null or [6][C] (common.h, BnLoad): the coefficients of the loader-fused backward
+    unsigned long long* acc;         // non-null: the sums leave as two-tier fixed-point atomic adds (common.h bn_acc2_add), no partial rows
 };
 // what one channel's sums become: coeffs[3][C] for bn_bwd_apply_kernel and / or bwd_coef[6][C] for the fused loaders
 __device__ __forceinline__ void bn_bwd_coeffs(int c, int C, float s1, float s2, float count, int training, const float* __restrict__ gamma,
@@ -349,7 +350,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
             float tot = 0.f;
             for (int q = 0; q < nparts; ++q) tot += spart[nparts == 1 ? (int)threadIdx.x : q * nout + (int)threadIdx.x];
             const int cvv = oo / (2 * V), j = oo % (2 * V);
-            store_part(&parts[((size_t)blockIdx.x * 2 + (j >= V)) * C + cvv * V + (j % V)], tot);
+            if (fin.acc) bn_acc2_add(fin.acc, (j >= V) * C + cvv * V + (j % V), C, tot);
+            else store_part(&parts[((size_t)blockIdx.x * 2 + (j >= V)) * C + cvv * V + (j % V)], tot);
         }
     }
     if (fin.counter && last_block_arrives(fin.counter, gridDim.x)) {      // the body of bn_bwd_finalize_kernel, by the last block
@@ -377,21 +379,41 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (threadIdx.x == 0) bn_bwd_coeffs(c, C, s1, s2, count, training, gamma, saved, coeffs, bwd_coef, ggamma, gbeta);
 }
 
-// graw = a*(dz - b - xhat*c), dz recomputed from (raw, gy[, gpool])
-template <typename T, bool POOL>
+// graw = a*(dz - b - xhat*c), dz recomputed from (raw, gy[, gpool]).  ACC: the coefficients come from the reduce kernel's fixed-point
+// accumulator (every block works them out in a prologue, block 0 also writes ggamma / gbeta): no finalize launch.
+struct BnBwdAccArgs {
+    const unsigned long long* acc;
+    const float* gamma; float* ggamma; float* gbeta;
+    float count; int training;
+};
+template <typename T, bool POOL, bool ACC = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ raw, const T* __restrict__ gy, const T* __restrict__ gpool,
                                                            int N, int H, int W, int C, const float* __restrict__ saved,
-                                                           const float* __restrict__ coeffs, T* __restrict__ graw, BnGy2<T> g2) {
+                                                           const float* __restrict__ coeffs, T* __restrict__ graw, BnGy2<T> g2,
+                                                           BnBwdAccArgs ba = BnBwdAccArgs{}) {
     constexpr int V = VT<T>::V;
     typedef typename VT<T>::Raw Raw;
     const int CV = C / V;
     const int64_t gthreads = (int64_t)gridDim.x * 256, gid = blockIdx.x * 256LL + threadIdx.x;
     const int cv = gid % CV;
+    __shared__ float cf_lds[ACC ? 3 * kBnAccMaxC : 1];
+    if (ACC) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float s1 = bn_acc2_value(ba.acc, c, C), s2 = bn_acc2_value(ba.acc, C + c, C);
+            cf_lds[c] = ba.gamma[c] * saved[C + c];
+            cf_lds[kBnAccMaxC + c] = ba.training ? s1 / ba.count : 0.f;
+            cf_lds[2 * kBnAccMaxC + c] = ba.training ? s2 / ba.count : 0.f;
+            if (blockIdx.x == 0) { ba.gbeta[c] = s1; ba.ggamma[c] = s2; }
+        }
+        __syncthreads();
+    }
     float mean[V], invstd[V], ca[V], cb[V], cc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = cv * V + i;
-        mean[i] = saved[c]; invstd[i] = saved[C + c]; ca[i] = coeffs[c]; cb[i] = coeffs[C + c]; cc[i] = coeffs[2 * C + c];
+        mean[i] = saved[c]; invstd[i] = saved[C + c];
+        if (ACC) { ca[i] = cf_lds[c]; cb[i] = cf_lds[kBnAccMaxC + c]; cc[i] = cf_lds[2 * kBnAccMaxC + c]; }
+        else { ca[i] = coeffs[c]; cb[i] = coeffs[C + c]; cc[i] = coeffs[2 * C + c]; }
     }
     bn_dz_foreach<T, POOL>(raw, gy, gpool, N, H, W, C, saved, gid / CV, gthreads / CV, cv, g2, [&](int64_t o, const float* fr, const float* dz) {
         float fd[V];
@@ -592,8 +614,9 @@ extern "C" int64_t miseg_bn_bwd_ws_bytes(int64_t N, int64_t H, int64_t W, int64_
 static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* gy, const void* gpool, int64_t N, int64_t H, int64_t W, int64_t C,
                             const float* gamma, const float* saved, int training, void* graw, float* ggamma, float* gbeta, void* ws,
                             int64_t ws_bytes, int32_t* sync_counter, float* bwd_coef, const void* gy2 = nullptr, int64_t n2_begin = 0,
-                            int64_t n2_end = 0) {
+                            int64_t n2_end = 0, void* acc = nullptr) {
     MISEG_REQUIRE(raw && (gy || gpool) && gamma && saved && (graw || bwd_coef) && ggamma && gbeta && ws, "bn_relu_bwd: null pointer");
+    MISEG_REQUIRE(!acc || (graw && !bwd_coef && !sync_counter && C <= kBnAccMaxC && ((uintptr_t)acc & 7) == 0), "bn_relu_bwd_acc: needs the apply pass, C <= 256 and an 8-byte aligned accumulator");
     MISEG_REQUIRE(!gy2 || (0 <= n2_begin && n2_begin < n2_end && n2_end <= N && (gy || gpool)), "bn_relu_bwd: bad sample range of the second gradient");
     const int V = dt == MISEG_BF16 ? 8 : 4;
     const int CV = (int)(C / V);
@@ -610,7 +633,9 @@ static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* g
     // one block (common.h, "last block finishes"); its scratch is the reduce's own LDS, widened to 1024 + 2C floats if need be
     const bool finish = sync_counter && C % 4 == 0 && C <= 256 && (int64_t)nb * 2 * C <= kFinishFloats;
     const size_t lb = std::max<size_t>((size_t)256 * 2 * V * 4, finish ? (size_t)(1024 + 2 * C) * 4 : 0);
-    BnBwdFinish fin{finish ? reinterpret_cast<unsigned int*>(sync_counter) : nullptr, gamma, coeffs, ggamma, gbeta, (float)npix, training, bwd_coef};
+    BnBwdFinish fin{finish ? reinterpret_cast<unsigned int*>(sync_counter) : nullptr, gamma, coeffs, ggamma, gbeta, (float)npix, training, bwd_coef,
+                    static_cast<unsigned long long*>(acc)};
+    MISEG_REQUIRE(!acc || nb <= kBnAccMaxBlocks, "bn_relu_bwd_acc: %d reduce blocks exceed the accumulator's no-wrap bound", nb);
     const int64_t p2lo = n2_begin * H * W, p2hi = n2_end * H * W;
 #define RED(TT, POOL) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<TT, POOL>), dim3(nb), dim3(256), lb, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, parts, fin, BnGy2<TT>{(const TT*)gy2, p2lo, p2hi})
     if (dt == MISEG_F32) { if (gpool) RED(float, true); else RED(float, false); }
@@ -618,16 +643,22 @@ static int bn_relu_bwd_impl(void* stream, int dt, const void* raw, const void* g
     else return fail(MISEG_E_INVALID, "bn_relu_bwd: bad dtype");
 #undef RED
     MISEG_LAUNCH_CHECK("bn_relu_bwd_reduce_kernel");
-    if (!finish) {
+    if (!finish && !acc) {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, parts, nb, (int)C, (float)npix, gamma, saved, training, coeffs, ggamma, gbeta, bwd_coef);
         MISEG_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     }
     if (!graw) return MISEG_OK;
     // elementwise pass: many more blocks than the reduce (no partials to bound), same thread -> channel-vector mapping
     const int na = ew_blocks((gpool ? npix / 4 : npix) * CV);
-#define APP(TT, POOL) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw, BnGy2<TT>{(const TT*)gy2, p2lo, p2hi})
-    if (dt == MISEG_F32) { if (gpool) APP(float, true); else APP(float, false); }
-    else { if (gpool) APP(bf16, true); else APP(bf16, false); }
+    const BnBwdAccArgs ba{static_cast<const unsigned long long*>(acc), gamma, ggamma, gbeta, (float)npix, training};
+#define APP(TT, POOL, ACCV) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, POOL, ACCV>), dim3(na), dim3(256), 0, st, (const TT*)raw, (const TT*)gy, (const TT*)gpool, (int)N, (int)H, (int)W, (int)C, saved, coeffs, (TT*)graw, BnGy2<TT>{(const TT*)gy2, p2lo, p2hi}, ba)
+    if (acc) {
+        if (dt == MISEG_F32) { if (gpool) APP(float, true, true); else APP(float, false, true); }
+        else { if (gpool) APP(bf16, true, true); else APP(bf16, false, true); }
+    } else {
+        if (dt == MISEG_F32) { if (gpool) APP(float, true, false); else APP(float, false, false); }
+        else { if (gpool) APP(bf16, true, false); else APP(bf16, false, false); }
+    }
 #undef APP
     MISEG_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return MISEG_OK;
@@ -652,6 +683,24 @@ extern "C" int miseg_bn_relu_bwd_dual(void* stream, int dt, const void* raw, con
                           ggamma, gbeta, ws, ws_bytes);
     MISEG_REQUIRE(graw, "bn_relu_bwd_dual: null pointer");
     return bn_relu_bwd_impl(stream, dt, raw, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, nullptr, nullptr, gy2, n2_begin, n2_end);
+}
+
+// miseg_bn_relu_bwd_dual in two launches: the reduce kernel's blocks add their sums into acc (uint64[4 C + 2], zero before the launch; two
+// fixed-point tiers, common.h bn_acc2_add), the apply kernel turns them into coefficients itself -- no partial rows, no finalize launch
+extern "C" int miseg_bn_relu_bwd_dual_acc(void* stream, int dt, const void* raw, const void* gy, const void* gpool, const void* gy2, int64_t n2_begin,
+                                          int64_t n2_end, int64_t N, int64_t H, int64_t W, int64_t C, const float* gamma, const float* saved,
+                                          int training, void* graw, float* ggamma, float* gbeta, void* ws, int64_t ws_bytes, void* acc) {
+    MISEG_TAPE(miseg_bn_relu_bwd_dual_acc, stream, dt, raw, gy, gpool, gy2, n2_begin, n2_end, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, acc);
+    MISEG_F16_DISPATCH_ON(dt, miseg_bn_relu_bwd_dual_acc, stream, MISEG_BF16, raw, gy, gpool, gy2, n2_begin, n2_end, N, H, W, C, gamma, saved, training, graw,
+                          ggamma, gbeta, ws, ws_bytes, acc);
+    MISEG_REQUIRE(graw && acc, "bn_relu_bwd_dual_acc: null pointer");
+    return bn_relu_bwd_impl(stream, dt, raw, gy, gpool, N, H, W, C, gamma, saved, training, graw, ggamma, gbeta, ws, ws_bytes, nullptr, nullptr, gy2, n2_begin, n2_end, acc);
+}
+
+extern "C" int64_t miseg_bn_relu_bwd_acc_supported(int dt, int64_t N, int64_t H, int64_t W, int64_t C) {
+    const int V = (dt == MISEG_F32) ? 4 : 8;
+    if (C % V || C > kBnAccMaxC || 256 % (C / V)) return 0;
+    return red_blocks(N * H * W, (int)(C / V)) <= kBnAccMaxBlocks;
 }
 
 // finalize + apply only: the per-block sums (sum dz, sum dz * xhat) were taken by the epilogue of the data-gradient convolution that

@@ -285,6 +285,22 @@ __device__ __forceinline__ void bn_acc_add(unsigned long long* acc, unsigned lon
 __device__ __forceinline__ double bn_acc_value(unsigned long long raw, unsigned long long misfit) {
     return misfit ? __builtin_nan("") : (double)(long long)raw * (1.0 / (double)kBnAccScale);
 }
+// The same for the BACKWARD's sums (sum dz, sum dz * xhat): gradients span many decades and, in the fp16 mode, carry the loss scale, so
+// one scale does not do.  Two tiers: 2^-40 units for block sums below 2^10 (gradients as they come), 2^-12 units for block sums below
+// 2^38 (loss-scaled ones); a block adds to every tier its sum fits and counts a misfit in the others; the consumer takes the finest
+// tier without a misfit.  Layout: acc[0 .. 2C) fine sums, acc[2C .. 4C) coarse sums, acc[4C], acc[4C + 1] the two misfit counts.
+constexpr float kBnAccFine = 1099511627776.f, kBnAccCoarse = 4096.f;
+__device__ __forceinline__ void bn_acc2_add(unsigned long long* acc, int idx, int C, float v) {
+    if (fabsf(v) < 1024.f) __hip_atomic_fetch_add(acc + idx, (unsigned long long)__float2ll_rn(v * kBnAccFine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(acc + 4 * C, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fabsf(v) < 2.7487e11f) __hip_atomic_fetch_add(acc + 2 * C + idx, (unsigned long long)__float2ll_rn(v * kBnAccCoarse), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(acc + 4 * C + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float bn_acc2_value(const unsigned long long* acc, int idx, int C) {
+    if (acc[4 * C] == 0) return (float)((double)(long long)acc[idx] * (1.0 / (double)kBnAccFine));
+    if (acc[4 * C + 1] == 0) return (float)((double)(long long)acc[2 * C + idx] * (1.0 / (double)kBnAccCoarse));
+    return __builtin_nanf("");
+}
 __device__ __forceinline__ void bn_finish_block(const float* __restrict__ parts, int nparts, int C, const BnFinish& f, float* lds) {
     const float* sums = block_column_sums(parts, nparts, 2 * C, lds);      // [sum | sum of squares] per channel
     for (int c = threadIdx.x; c < C; c += 256) {

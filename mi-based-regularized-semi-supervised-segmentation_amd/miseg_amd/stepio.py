@@ -24,7 +24,9 @@ from ._cabi import call
 FLIPS_OFF, FLIPS_CAP = 0, 512                 # int32
 HYPER_OFF, HYPER_CAP = 2048, 64               # float32: 8 per parameter group (lr/bc1, 1/sqrt(bc2), eps, wd, 1/loss scale)
 COUNT_OFF, COUNT_CAP = 2304, 64               # int32, zero on the host: the upload zeroes the counters
-SEED_OFF, ACC_OFF, PARAM_BYTES = 2560, 32768, 65536
+import os as _os
+# (the opt-in accumulators of the BatchNorm backward need 6 892 more words)
+SEED_OFF, ACC_OFF, PARAM_BYTES = 2560, 32768, 131072 if _os.environ.get("MISEG_BN_ACC_BWD", "0") == "1" else 65536
 SEED_CAP = (ACC_OFF - SEED_OFF) // 4
 ACC_CAP = (PARAM_BYTES - ACC_OFF) // 8        # int64, zero on the host: the BatchNorm statistics accumulators (miseg_conv3x3_fwd_acc)
 ARENA_FLOATS = 8192

@@ -66,6 +66,10 @@ _RED_ONLY = os.environ.get("MISEG_BN_RED", "0") == "1" and not _FUSE_BN_BWD
 # 1 (default): the forward statistics leave the convolution as fixed-point atomic adds and the apply kernel finishes them itself
 # (miseg_conv3x3_fwd_acc / miseg_bn_relu_fwd_acc): 22 launches fewer per step.  0: one partial row per block + miseg_bn_finalize.
 _BN_ACC = os.environ.get("MISEG_BN_ACC", "1") != "0"
+# The same for the backward's sums (two fixed-point tiers, miseg_bn_relu_bwd_dual_acc).  Built and measured, OFF: the reduce kernel's
+# blocks all finish together, so their atomics arrive as one burst on a few lines (+8 us per launch) and the apply prologue costs 5 us
+# -- more than the finalize launch they replace (6 us + a launch boundary).  DESIGN.md section 10.
+_BN_ACC_BWD = os.environ.get("MISEG_BN_ACC_BWD", "0") == "1"
 
 
 class _BnRec:
@@ -375,11 +379,21 @@ class _ConvBNReLU(torch.autograd.Function):
         if gbeta is None:
             gbeta = torch.empty(cout, dtype=torch.float32, device=dev)
         ws = _ws(query("miseg_bn_bwd_ws_bytes", n, h, w, cout), dev)
+        bacc = None
+        if _BN_ACC_BWD and not SYNC_COUNTERS.enabled and query("miseg_bn_relu_bwd_acc_supported", _DT[dtype], n, h, w, cout):
+            # the reduce kernel adds its sums into a zeroed two-tier fixed-point accumulator, the apply kernel finishes them: no finalize launch
+            io = stepio.current()
+            bacc = io.acc64(4 * cout + 2) if io is not None else torch.zeros(4 * cout + 2, dtype=torch.int64, device=dev)   # (None: block full -> finalize path)
         if ext_parts is not None and not extras and gpool is None and gy is not None and not want_pool and dtype != torch.float16:
             # the data-gradient kernel that wrote gy has summed dz and dz * xhat per block in its epilogue: finalize + apply only
             call("miseg_bn_relu_bwd_ext", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), n, h, w, cout, _ptr(gamma), _ptr(saved), int(training),
                  _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ext_parts), ext_nparts, _ptr(ws), ws.numel(),
                  work=(0.0, float(raw.element_size()) * n * h * w * cout * 3.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
+        elif bacc is not None:
+            g2, n0, n1 = (as_nhwc(extra[0]), extra[1], extra[2]) if extra is not None else (None, 0, 0)
+            call("miseg_bn_relu_bwd_dual_acc", _stream(), _DT[dtype], _ptr(raw), _ptr(gy), _ptr(gpool), _ptr(g2), n0, n1, n, h, w, cout, _ptr(gamma),
+                 _ptr(saved), int(training), _ptr(graw), _ptr(ggamma), _ptr(gbeta), _ptr(ws), ws.numel(), _ptr(bacc),
+                 work=(0.0, float(raw.element_size()) * n * h * w * cout * 5.0), tag=f"bn_relu_bwd[{h}x{w},{cout}]")
         elif extra is not None:
             g2, n0, n1, _ = extra
             g2 = as_nhwc(g2)

@@ -272,8 +272,8 @@ def test_bn_statistics_finished_by_the_last_block_equal_the_separate_finalize(sh
                                    (8, 32, 32, 128, 128)])
 def test_bn_statistics_as_fixed_point_accumulators_equal_the_finalize_launch(shape, dtype, monkeypatch):
     """miseg_conv3x3_fwd_acc + miseg_bn_relu_fwd_acc (the shipped training path: every block of the convolution adds its channel sums to
-    one int64 accumulator, the apply kernel finishes the statistics in its prologue) against miseg_conv3x3_fwd + miseg_bn_finalize +
-    miseg_bn_relu_fwd: same per-block sums, exacter total -> 2e-6 relative on every statistic and gradient (16-bit outputs: one ulp);
+    one int64 accumulator, the apply kernel finishes the statistics in its prologue; and miseg_bn_relu_bwd_dual_acc, the opt-in twin for
+    the backward's sums) against miseg_conv3x3_fwd + miseg_bn_finalize + miseg_bn_relu_fwd (and the backward with its finalize launch): same per-block sums, exacter total -> 2e-6 relative on every statistic and gradient (16-bit outputs: one ulp);
     streaming, persistent tiled and per-tile kernels, pooled and unpooled apply kernels.  Two runs of the accumulator path are
     IDENTICAL bit for bit (integer adds do not care about the order the blocks arrive in)."""
     from miseg_amd import unet_ops
@@ -286,6 +286,7 @@ def test_bn_statistics_as_fixed_point_accumulators_equal_the_finalize_launch(sha
 
     def run(acc):
         monkeypatch.setattr(unet_ops, "_BN_ACC", acc)
+        monkeypatch.setattr(unet_ops, "_BN_ACC_BWD", acc)         # (the backward's two-tier accumulators: opt-in, same parity bar)
         bn = {k: v.to(DEV) for k, v in make_bn(cout, f"bnacc/{shape}/bn").items()}
         xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
         gd, bd = bn["weight"].clone().requires_grad_(True), bn["bias"].clone().requires_grad_(True)
