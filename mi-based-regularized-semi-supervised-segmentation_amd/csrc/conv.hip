@@ -379,34 +379,46 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_pt_kernel(ConvSrc src, int
     // on the matrix cores, across tile boundaries: set A / set B alternate (static register names: the stage loop is unrolled by two).
     uint4 pinA[NIS], pwtA[NWS], pinB[DEPTH == 2 ? NIS : 1], pwtB[DEPTH == 2 ? NWS : 1];
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    auto fetch = [&](uint4 (&pin)[NIS], uint4 (&pwt)[NWS], int n, int h0, int w0, int c0) __attribute__((always_inline)) {
+    // A thread's slots of the haloed input tile and of the weight slice never change: pixel, channel vector, tap, output channel.  Their
+    // geometry is worked out once; a stage adds the tile's corner and the chunk's first channel (both block-uniform) and tests ranges.
+    // (Derived per stage, the index math was most of this kernel's 6.4 vector instructions per MFMA: profiles/r04_pmc.json.)
+    constexpr int CV4 = CK / VEC;
+    int i_iy[NIS], i_ix[NIS], i_cv[NIS], i_rel0[NIS], i_rel1[NIS];       // row - 1, column - 1, channel offset in the chunk (< 0: no slot), offsets inside source 0 / 1
+    int w_cv[NWS], w_rel[NWS];                                            // channel offset in the chunk (< 0: no slot), offset of (tap, co) in the packed weights
+    {
+        const int ws0 = W >> src.ups0, ws1 = W >> src.ups1;
 #pragma unroll
         for (int j = 0; j < NIS; ++j) {
-            const int idx = tid + kCT * j;
-            const int v = idx % (CK / VEC), px = idx / (CK / VEC), ix = px % IW, iy = px / IW;
-            const int h = h0 - 1 + iy, w = w0 - 1 + ix, c = c0 + v * VEC;
-            uint4 val = zero4;
-            if (idx < IH * IW * (CK / VEC) && h >= 0 && h < H && w >= 0 && w < W && c < Cin) {
-                const T* sp;
-                if (c < src.C0) {
-                    const int hs = H >> src.ups0, wsz = W >> src.ups0;
-                    sp = reinterpret_cast<const T*>(src.p0) + (((size_t)n * hs + (h >> src.ups0)) * wsz + (w >> src.ups0)) * src.C0 + c;
-                } else {
-                    const int hs = H >> src.ups1, wsz = W >> src.ups1;
-                    sp = reinterpret_cast<const T*>(src.p1) + (((size_t)n * hs + (h >> src.ups1)) * wsz + (w >> src.ups1)) * src.C1 + (c - src.C0);
-                }
-                val = *reinterpret_cast<const uint4*>(sp);
-            }
-            pin[j] = val;
+            const int idx = tid + kCT * j, v = idx % CV4, px = idx / CV4;
+            i_ix[j] = px % IW - 1, i_iy[j] = px / IW - 1;
+            i_cv[j] = idx < IH * IW * CV4 ? v * VEC : -1;
+            // (h0 + d) >> ups = (h0 >> ups) + (d >> ups): tile corners are multiples of THT x TW, the shift is arithmetic (d = -1 stays outside)
+            i_rel0[j] = ((i_iy[j] >> src.ups0) * ws0 + (i_ix[j] >> src.ups0)) * src.C0 + v * VEC;
+            i_rel1[j] = ((i_iy[j] >> src.ups1) * ws1 + (i_ix[j] >> src.ups1)) * src.C1 + v * VEC - src.C0;
         }
 #pragma unroll
         for (int j = 0; j < NWS; ++j) {
-            const int idx = tid + kCT * j;
-            const int v = idx % (CK / VEC), co = (idx / (CK / VEC)) % COT, tap = idx / ((CK / VEC) * COT);
-            const int c = c0 + v * VEC;
+            const int idx = tid + kCT * j, v = idx % CV4, co = (idx / CV4) % COT, tap = idx / (CV4 * COT);
+            w_cv[j] = (idx < 9 * COT * CV4 && co0 + co < Cout) ? v * VEC : -1;
+            w_rel[j] = (tap * Cout + co0 + co) * Cin + v * VEC;
+        }
+    }
+    auto fetch = [&](uint4 (&pin)[NIS], uint4 (&pwt)[NWS], int n, int h0, int w0, int c0) __attribute__((always_inline)) {
+        const T* s0 = reinterpret_cast<const T*>(src.p0) + (((size_t)n * (H >> src.ups0) + (h0 >> src.ups0)) * (W >> src.ups0) + (w0 >> src.ups0)) * src.C0 + c0;
+        const T* s1 = reinterpret_cast<const T*>(src.p1) + (((size_t)n * (H >> src.ups1) + (h0 >> src.ups1)) * (W >> src.ups1) + (w0 >> src.ups1)) * src.C1 + c0;
+#pragma unroll
+        for (int j = 0; j < NIS; ++j) {
+            const int c = c0 + i_cv[j];
             uint4 val = zero4;
-            if (idx < 9 * COT * (CK / VEC) && co0 + co < Cout && c < Cin)
-                val = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * Cout + co0 + co) * Cin + c);
+            if (i_cv[j] >= 0 && c < Cin && (unsigned)(h0 + i_iy[j]) < (unsigned)H && (unsigned)(w0 + i_ix[j]) < (unsigned)W)
+                val = *reinterpret_cast<const uint4*>(c < src.C0 ? s0 + i_rel0[j] : s1 + i_rel1[j]);
+            pin[j] = val;
+        }
+        const T* wc = wpk + c0;
+#pragma unroll
+        for (int j = 0; j < NWS; ++j) {
+            uint4 val = zero4;
+            if (w_cv[j] >= 0 && c0 + w_cv[j] < Cin) val = *reinterpret_cast<const uint4*>(wc + w_rel[j]);
             pwt[j] = val;
         }
     };
@@ -1631,7 +1643,8 @@ static int64_t stream_blocks(int64_t N, int64_t H, int64_t W) {
 // fills the chip once: two blocks per CU for the 8-row tiles (60 KB of LDS each), one for the 16-row tiles.
 struct PtGrid { int blocks, per; };
 static inline PtGrid pt_grid(int ntiles, int slices, int th) {
-    const int target = std::max(1, (256 * (th == 8 ? 2 : 1)) / std::max(1, slices));
+    static const int per_cu = [] { const char* e = getenv("MISEG_PT_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();     // diagnostic: 1, 3, 4 measured slower
+    const int target = std::max(1, (256 * (th == 8 ? per_cu : 1)) / std::max(1, slices));
     const int per = std::max(1, (ntiles + target - 1) / target);
     return PtGrid{(ntiles + per - 1) / per, per};
 }
