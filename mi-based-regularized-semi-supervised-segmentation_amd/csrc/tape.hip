@@ -211,9 +211,30 @@ extern "C" int miseg_tape_replay(int64_t tape, int64_t segment, const void* cons
 }
 
 // ---- pinned-memory traffic and events as entry points (so that they are on the tape) -------------------------------------------------
+// The iteration's one host -> device copy.  From pinned (device-mapped) host memory it is a KERNEL that reads the host block over the bus:
+// hipMemcpyAsync hands a 64 KB host-to-device copy to the DMA engine, and the hand-over between the engines cost the stream ~21 us
+// of idle time at every step boundary (profiles/r04d_critical_path: the gap between the download and the step's first kernel).
+typedef unsigned int tape_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void upload_kernel(tape_u32x4* __restrict__ dst, const tape_u32x4* __restrict__ src, int n16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 extern "C" int miseg_upload(void* stream, void* dst_dev, const void* src_pinned, int64_t nbytes) {
     MISEG_TAPE(miseg_upload, stream, dst_dev, src_pinned, nbytes);
     if (nbytes <= 0) return MISEG_OK;
+    static const bool by_kernel = [] { const char* e = getenv("MISEG_UPLOAD_KERNEL"); return !e || atoi(e) != 0; }();
+    hipPointerAttribute_t at;
+    if (by_kernel && nbytes % 16 == 0 && (((uintptr_t)dst_dev | (uintptr_t)src_pinned) & 15) == 0 &&
+        hipPointerGetAttributes(&at, src_pinned) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+        const int n16 = (int)(nbytes / 16);
+        hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           static_cast<tape_u32x4*>(dst_dev), static_cast<const tape_u32x4*>(at.devicePointer), n16);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return miseg_core::fail(MISEG_E_LAUNCH, "upload: %s", hipGetErrorString(e));
+        return MISEG_OK;
+    }
+    (void)hipGetLastError();      // (a pointer the runtime does not know: not an error of this call)
     hipError_t e = hipMemcpyAsync(dst_dev, src_pinned, (size_t)nbytes, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return miseg_core::fail(MISEG_E_LAUNCH, "upload: %s", hipGetErrorString(e));
     return MISEG_OK;
