@@ -44,6 +44,7 @@ from miseg_amd.tape import keep as _keep
 from semi_seg._utils import FeatureExtractor, IICLossWrapper, ProjectorWrapper
 
 _DEBUG_ASSERTS = os.environ.get("MISEG_ASSERTS", "0") == "1"
+_READBACK_EARLY = os.environ.get("MISEG_READBACK_EARLY", "1") != "0"     # Dice counts + report launched before backward (0: after it, on the step's tail)
 _GUARD_STEP = os.environ.get("MISEG_GUARD_STEP", "1") != "0"   # a failed deferred check turns the iteration's Adam launch into a no-op
 
 
@@ -458,6 +459,17 @@ class TrainEpocher(_num_class_mixin, _Epocher):
                 unlabeled_logits=unlabel_logits, flips=flips, num_unlabeled=ub,
             )
         total_loss = sup_loss + self._reg_weight * reg_loss
+        # Everything the read-back needs from the FORWARD pass is launched here, before backward: the Dice counts and the iteration's
+        # report (meter values + the simplex / NaN flags that guard the update).  Issued after backward they sat behind the optimiser's
+        # wait for the weight-gradient stream, i.e. on the step's tail (~19 us); here they run while the main stream waits for the IIC chain.
+        def forward_readback():
+            with torch.no_grad():
+                self._pending.put("sup_loss", sup_loss)
+                self._pending.put("reg_loss", reg_loss)
+                dice = ops.argmax_dice(label_logits.detach(), labels, want_pred=False, to_host=True)
+            return dice[1], dice[2], (self._pending.precompute() if _GUARD_STEP and hasattr(self._optimizer, "apply") else None)
+        if _READBACK_EARLY:
+            inter, union, guard = forward_readback()
         self._optimizer.zero_grad()
         if self._reducer is not None:
             self._reducer.prepare()
@@ -472,17 +484,13 @@ class TrainEpocher(_num_class_mixin, _Epocher):
             total_loss.backward()
         if self._reducer is not None:
             self._reducer.finish()
-        with torch.no_grad():
-            self._pending.put("sup_loss", sup_loss)
-            self._pending.put("reg_loss", reg_loss)
         io = stepio.CURRENT
-        with torch.no_grad():      # (before the optimiser launch, which first waits for the weight-gradient stream: these run under that tail)
-            _, inter, union = ops.argmax_dice(label_logits.detach(), labels, want_pred=False, to_host=True)
+        if not _READBACK_EARLY:
+            inter, union, guard = forward_readback()
         if hasattr(self._optimizer, "apply"):
-            # The iteration's report (meter values + the simplex / NaN flags) is computed here, in one launch, and its flags guard
-            # the update on the device: the host raises a failed check one iteration late, but it has not moved the weights
-            # (the reference raises before backward).
-            self._optimizer.apply(guard=self._pending.precompute() if _GUARD_STEP else None, io=io)
+            # The report's flags guard the update on the device: the host raises a failed check one iteration late, but it has not moved
+            # the weights (the reference raises before backward).
+            self._optimizer.apply(guard=guard, io=io)
         else:
             self._optimizer.step()
         self._overflow = getattr(self._optimizer, "last_nonfinite", None)     # device float[1] in the fp16 mode, else None
