@@ -438,6 +438,18 @@ int miseg_bn_relu_fwd(void* stream, int dt, const void* raw, int64_t N, int64_t 
  * NaN).  Shapes: miseg_conv3x3_fwd_acc_supported (Cout <= 256, at most 2 048 blocks: the no-wrap bound).  miseg_bn_relu_fwd_acc =
  * miseg_bn_finalize + miseg_bn_relu_fwd: every block turns the totals into scale / shift itself, block 0 writes `saved`
  * ([mean | invstd | scale | shift], what the backward reads) and moves running_mean / running_var / num_batches_tracked.  C <= 256. */
+/* The stem convolution and its weight gradient without matrix cores (ref contrastyou/arch/unet.py:58: `conv_block(input_dim = 1, 16)`'s
+ * first Conv2d): x = [N][H][W][CP] whose channel 0 is the image -- in 16-bit storage (the padded channel vector the other entry points
+ * take; x_f32 = 0) or the fp32 image itself (x_f32 = 1, CP = 1: rounded to the storage type as it is read, so the padded copy need
+ * not exist) --, w = the fp32 master weight [Cout][Cin_weight = 1][3][3].  A thread owns a pixel and four output channels; products and
+ * accumulation as on the MFMA path (16-bit operands, fp32 sums).  acc_or_null: the BatchNorm accumulator of miseg_conv3x3_fwd_acc
+ * (training) or null (evaluation).  miseg_conv3x3_stem_wgrad writes gw [Cout][1][3][3] (no padded gradient, no slice). */
+int64_t miseg_conv3x3_stem_supported(int dt, int64_t Cin_weight, int64_t CP, int64_t Cout);
+int miseg_conv3x3_stem_fwd(void* stream, int dt, const void* x, int x_f32, int64_t CP, int64_t N, int64_t H, int64_t W, const float* w,
+                           int64_t Cin_weight, int64_t Cout, void* out, void* acc_or_null);
+int64_t miseg_conv3x3_stem_wgrad_ws_bytes(int64_t Cout);
+int miseg_conv3x3_stem_wgrad(void* stream, int dt, const void* x, int x_f32, int64_t CP, int64_t N, int64_t H, int64_t W, const void* graw,
+                             int64_t Cout, float* gw, void* ws, int64_t ws_bytes);
 int64_t miseg_conv3x3_fwd_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout);
 int miseg_conv3x3_fwd_acc(void* stream, int dt, const void* in0, int64_t C0, int ups0, const void* in1, int64_t C1, int ups1,
                           int64_t N, int64_t H, int64_t W, const void* packed_w, int64_t Cout, void* out, void* acc);

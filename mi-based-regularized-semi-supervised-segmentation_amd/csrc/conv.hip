@@ -1570,6 +1570,129 @@ __global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict
     reduce_partials_block(partials, nparts, (size_t)len, len, Split2Out{d0, n0, d1}, [](int e) { return (size_t)e; });
 }
 
+// ---- The stem (one image channel in, padded to a channel vector) without matrix cores -- an experiment, OFF by default
+// (MISEG_STEM_KERNELS=1).  `conv3x3_stream_kernel` treats the padded vector as 8 (of 32) input channels: 31 of 32
+// multiplies are by zero, and the launch takes 50 us at 256 x 256 for a 100 MB store; its weight gradient (59 us) is the LAST kernel of
+// the backward pass, alone on the GPU, i.e. all of it is step tail.  Measured: these kernels take 56 / 57 + 8 us -- the per-row
+// staging (load -> barrier -> compute, no prefetch) is latency-bound; nine direct loads per thread are worse (122 / 140 us).
+// Here a thread owns one pixel and four output channels: nine bf16 x bf16 products per output (exact in fp32, accumulated by FMA in tap order), 8-byte stores that
+// are contiguous across the lanes of a pixel; statistics from the fp32 accumulators as everywhere.  x: [N][H][W][CP] (channel 0 is the
+// image), w: the fp32 master [Cout][Cw][3][3] (Cw >= 1: only input channel 0 is read), rounded to the storage type as the packed
+// weights of the MFMA path are.
+template <typename T, typename TX>
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const TX* __restrict__ x, int CP, int N, int H, int W, const float* __restrict__ w, int Cw,
+                                                            int Cout, T* __restrict__ out, unsigned long long* __restrict__ acc) {
+    const int G = Cout / 4, g = threadIdx.x % G, ppb = 256 / G;
+    float wr[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[tap][r] = to_f32(from_f32<T>(w[((size_t)(g * 4 + r) * Cw) * 9 + tap]));
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // A block walks whole image rows (row = n * H + h: block-uniform, so is h); the three input rows a row needs are staged in LDS first,
+    // one 2-byte load per pixel and row (read per thread, the nine taps of a pixel were 36 narrow loads: the kernel ran at the
+    // load unit's instruction rate, 148 us).  Rows / columns outside the image are zeros in the buffer.
+    extern __shared__ unsigned short stem_rows[];        // [3][W + 2]
+    const int rows = N * H, c0 = threadIdx.x / G, RB = W + 2;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+      const int h = row % H;
+      {
+          __syncthreads();
+          for (int i = threadIdx.x; i < 3 * RB; i += 256) {
+              const int rr = i / RB, c = i - rr * RB - 1, hh = h + rr - 1;
+              T v = from_f32<T>(0.f);
+              if ((unsigned)hh < (unsigned)H && (unsigned)c < (unsigned)W) v = from_f32<T>(to_f32(x[((size_t)(row + rr - 1) * W + c) * CP]));
+              stem_rows[i] = *reinterpret_cast<const unsigned short*>(&v);
+          }
+          __syncthreads();
+      }
+      for (int wq = c0; wq < W; wq += ppb) {
+        const size_t p = (size_t)row * W + wq;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = bf16_bits_to_f32(stem_rows[(tap / 3) * RB + wq + tap % 3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = fmaf(v, wr[tap][r], a[r]);
+        }
+        T o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o4[r] = from_f32<T>(a[r]); s1[r] += a[r]; s2[r] += a[r] * a[r]; }
+        *reinterpret_cast<uint2*>(out + p * Cout + g * 4) = *reinterpret_cast<const uint2*>(o4);
+      }
+    }
+    if (acc) {       // block sums per channel (fixed order), then the fixed-point accumulator (common.h bn_acc_add)
+        __shared__ float sred[256][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sred[threadIdx.x][r] = s1[r]; sred[threadIdx.x][4 + r] = s2[r]; }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * Cout) {
+            const int which = threadIdx.x / Cout, c = threadIdx.x % Cout, gg = c / 4, r = c % 4;
+            float t = 0.f;
+            for (int m = 0; m < ppb; ++m) t += sred[m * G + gg][which * 4 + r];
+            bn_acc_add(acc + which * Cout + c, acc + 2 * Cout, t);
+        }
+    }
+}
+
+// gw[co][tap] = sum_px graw[px][co] * x[px + tap]: the same thread map, 36 accumulators per thread over the block's pixels, one partial
+// vector [Cout * 9] per block (summed by stem_wgrad_sum_kernel in fixed order: deterministic)
+template <typename T, typename TX>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ x, int CP, int N, int H, int W, const T* __restrict__ graw, int Cout,
+                                                         float* __restrict__ partials) {
+    const int G = Cout / 4, g = threadIdx.x % G, ppb = 256 / G;
+    float a[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[tap][r] = 0.f;
+    extern __shared__ float swr[];      // [256][37]: the threads' 36 sums (odd stride: conflict-free column reads); behind it the three staged input rows
+    unsigned short* stem_rows = reinterpret_cast<unsigned short*>(swr + 256 * 37);       // [3][W + 2]
+    const int rows = N * H, c0 = threadIdx.x / G, RB = W + 2;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+      const int h = row % H;
+      {
+          __syncthreads();
+          for (int i = threadIdx.x; i < 3 * RB; i += 256) {
+              const int rr = i / RB, c = i - rr * RB - 1, hh = h + rr - 1;
+              T v = from_f32<T>(0.f);
+              if ((unsigned)hh < (unsigned)H && (unsigned)c < (unsigned)W) v = from_f32<T>(to_f32(x[((size_t)(row + rr - 1) * W + c) * CP]));
+              stem_rows[i] = *reinterpret_cast<const unsigned short*>(&v);
+          }
+          __syncthreads();
+      }
+      for (int wq = c0; wq < W; wq += ppb) {
+        const size_t p = (size_t)row * W + wq;
+        const uint2 gq = *reinterpret_cast<const uint2*>(graw + p * Cout + g * 4);
+        T g4[4];
+        *reinterpret_cast<uint2*>(g4) = gq;
+        const float gv[4] = {to_f32(g4[0]), to_f32(g4[1]), to_f32(g4[2]), to_f32(g4[3])};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = bf16_bits_to_f32(stem_rows[(tap / 3) * RB + wq + tap % 3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[tap][r] = fmaf(gv[r], v, a[tap][r]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) swr[threadIdx.x * 37 + tap * 4 + r] = a[tap][r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < Cout * 9; o += 256) {
+        const int co = o / 9, tap = o % 9, gg = co / 4, r = co % 4;
+        float t = 0.f;
+        for (int m = 0; m < ppb; ++m) t += swr[(m * G + gg) * 37 + tap * 4 + r];
+        partials[(size_t)blockIdx.x * Cout * 9 + o] = t;
+    }
+}
+__global__ __launch_bounds__(256) void stem_wgrad_sum_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ gw) {
+    reduce_partials_block(partials, nparts, (size_t)len, len, gw, [](int e) { return (size_t)e; });
+}
+constexpr int kStemBlocks = 1024;
+
 static inline int tile_w(int64_t W) { return W >= 32 ? 32 : 16; }
 
 }  // namespace miseg
@@ -1899,6 +2022,55 @@ extern "C" int miseg_conv3x3_dgrad_bn(void* stream, int dt, const void* raw_or_g
 
 // The partial-sum matrix one finishing block reads: [parts][2 Cout] floats.  Above this the separate, C-block bn_finalize is faster.
 static const int64_t kBnFinishMaxFloats = [] { const char* e = getenv("MISEG_FINISH_FLOATS"); return e ? atoll(e) : 65536LL; }();
+
+// ---- the stem without matrix cores (one real input channel; see stem_conv_fwd_kernel)
+extern "C" int64_t miseg_conv3x3_stem_supported(int dt, int64_t Cin_weight, int64_t CP, int64_t Cout) {
+    return (dt == MISEG_BF16 || dt == MISEG_F16) && Cin_weight == 1 && CP >= 1 && Cout >= 4 && Cout <= 64 && Cout % 4 == 0 && 256 % (Cout / 4) == 0;     // (W <= 4096: LDS rows, checked per call)
+}
+
+extern "C" int miseg_conv3x3_stem_fwd(void* stream, int dt, const void* x, int x_f32, int64_t CP, int64_t N, int64_t H, int64_t W, const float* w,
+                                      int64_t Cin_weight, int64_t Cout, void* out, void* acc_or_null) {
+    MISEG_TAPE(miseg_conv3x3_stem_fwd, stream, dt, x, x_f32, CP, N, H, W, w, Cin_weight, Cout, out, acc_or_null);
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_stem_fwd, stream, MISEG_BF16, x, x_f32, CP, N, H, W, w, Cin_weight, Cout, out, acc_or_null);
+    MISEG_REQUIRE(x && w && out && N > 0 && H > 0 && W > 0, "conv3x3_stem_fwd: bad args");
+    MISEG_REQUIRE(miseg_conv3x3_stem_supported(dt, Cin_weight, CP, Cout), "conv3x3_stem_fwd: 16-bit storage, one weight input channel, Cout in {4, 8, 16, 32, 64}");
+    MISEG_REQUIRE(!acc_or_null || ((uintptr_t)acc_or_null & 7) == 0, "conv3x3_stem_fwd: the accumulator must be 8-byte aligned");
+    MISEG_REQUIRE(W <= 4096, "conv3x3_stem_fwd: rows of at most 4096 pixels");
+    const unsigned nb = (unsigned)std::min<int64_t>(N * H, kStemBlocks);
+    if (x_f32)
+        hipLaunchKernelGGL((stem_conv_fwd_kernel<bf16, float>), dim3(nb), dim3(256), (size_t)3 * (W + 2) * 2, as_stream(stream), (const float*)x, (int)CP, (int)N, (int)H, (int)W, w,
+                           (int)Cin_weight, (int)Cout, (bf16*)out, static_cast<unsigned long long*>(acc_or_null));
+    else
+        hipLaunchKernelGGL((stem_conv_fwd_kernel<bf16, bf16>), dim3(nb), dim3(256), (size_t)3 * (W + 2) * 2, as_stream(stream), (const bf16*)x, (int)CP, (int)N, (int)H, (int)W, w,
+                           (int)Cin_weight, (int)Cout, (bf16*)out, static_cast<unsigned long long*>(acc_or_null));
+    MISEG_LAUNCH_CHECK("stem_conv_fwd_kernel");
+    return MISEG_OK;
+}
+
+extern "C" int64_t miseg_conv3x3_stem_wgrad_ws_bytes(int64_t Cout) { return (int64_t)kStemBlocks * Cout * 9 * 4; }
+
+extern "C" int miseg_conv3x3_stem_wgrad(void* stream, int dt, const void* x, int x_f32, int64_t CP, int64_t N, int64_t H, int64_t W, const void* graw,
+                                        int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
+    MISEG_TAPE(miseg_conv3x3_stem_wgrad, stream, dt, x, x_f32, CP, N, H, W, graw, Cout, gw, ws, ws_bytes);
+    MISEG_F16_DISPATCH_ON(dt, miseg_conv3x3_stem_wgrad, stream, MISEG_BF16, x, x_f32, CP, N, H, W, graw, Cout, gw, ws, ws_bytes);
+    MISEG_REQUIRE(x && graw && gw && ws && N > 0 && H > 0 && W > 0, "conv3x3_stem_wgrad: bad args");
+    MISEG_REQUIRE(miseg_conv3x3_stem_supported(dt, 1, CP, Cout), "conv3x3_stem_wgrad: 16-bit storage, Cout in {4, 8, 16, 32, 64}");
+    MISEG_REQUIRE(ws_bytes >= miseg_conv3x3_stem_wgrad_ws_bytes(Cout), "conv3x3_stem_wgrad: workspace too small");
+    MISEG_REQUIRE(W <= 4096, "conv3x3_stem_wgrad: rows of at most 4096 pixels");
+    const unsigned nb = (unsigned)std::min<int64_t>(N * H, kStemBlocks);
+    hipStream_t st = as_stream(stream);
+    if (x_f32)
+        hipLaunchKernelGGL((stem_wgrad_kernel<bf16, float>), dim3(nb), dim3(256), (size_t)256 * 37 * 4 + (size_t)3 * (W + 2) * 2, st, (const float*)x, (int)CP, (int)N, (int)H, (int)W,
+                           (const bf16*)graw, (int)Cout, (float*)ws);
+    else
+        hipLaunchKernelGGL((stem_wgrad_kernel<bf16, bf16>), dim3(nb), dim3(256), (size_t)256 * 37 * 4 + (size_t)3 * (W + 2) * 2, st, (const bf16*)x, (int)CP, (int)N, (int)H, (int)W,
+                           (const bf16*)graw, (int)Cout, (float*)ws);
+    MISEG_LAUNCH_CHECK("stem_wgrad_kernel");
+    const int len = (int)(Cout * 9);
+    hipLaunchKernelGGL(stem_wgrad_sum_kernel, dim3(reduce_grid(len, nb)), dim3(256), 0, st, (const float*)ws, (int)nb, len, gw);
+    MISEG_LAUNCH_CHECK("stem_wgrad_sum_kernel");
+    return MISEG_OK;
+}
 
 extern "C" int64_t miseg_conv3x3_fwd_acc_supported(int dt, int64_t Cin, int64_t N, int64_t H, int64_t W, int64_t Cout) {
     return Cout <= 256 && miseg_conv3x3_fwd_parts(dt, Cin, N, H, W, Cout) <= kBnAccMaxBlocks;       // the fixed point's no-wrap bound

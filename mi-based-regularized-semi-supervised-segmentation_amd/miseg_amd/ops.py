@@ -1069,7 +1069,8 @@ def cat_flip(a: Tensor, b: Tensor, flips: Tensor, stem_dtype=None) -> Tensor:
     assert a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and a.element_size() == 4 and a.dim() == 4, (a.shape, b.shape, a.dtype)
     na, nb = a.shape[0], b.shape[0]
     out = torch.empty((na + 2 * nb,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
-    if stem_dtype in (torch.bfloat16, torch.float16) and a.dtype == torch.float32 and a.shape[1] == 1:
+    from . import unet_ops as _uo
+    if stem_dtype in (torch.bfloat16, torch.float16) and a.dtype == torch.float32 and a.shape[1] == 1 and not _uo._STEM_KERNELS:
         pad = empty_nhwc(na + 2 * nb, 8, a.shape[2], a.shape[3], stem_dtype, a.device)
         call("miseg_cat_flip_pad", _stream(), _ptr(a), na, _ptr(b), nb, a.shape[2], a.shape[3], _ptr(flips), _ptr(out), _DT[stem_dtype], _ptr(pad))
         out._miseg_stem = (stem_dtype, pad)

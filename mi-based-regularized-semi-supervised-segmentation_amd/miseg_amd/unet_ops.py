@@ -65,6 +65,10 @@ _FUSE_BN_RED = True      # ... including the statistics pass in the producing da
 _RED_ONLY = os.environ.get("MISEG_BN_RED", "0") == "1" and not _FUSE_BN_BWD
 # 1 (default): the forward statistics leave the convolution as fixed-point atomic adds and the apply kernel finishes them itself
 # (miseg_conv3x3_fwd_acc / miseg_bn_relu_fwd_acc): 22 launches fewer per step.  0: one partial row per block + miseg_bn_finalize.
+# 1: the stem (one image channel) through its own pixel-per-thread kernels reading the fp32 image, instead of the streaming MFMA convolution
+# and the tiled weight gradient on a padded channel vector.  Built, parity-tested, not faster (56 vs 50 us forward, 57 + 8 vs 59 + 10 us
+# weight gradient; the padded operand's 15 us launch becomes 4): OFF.  DESIGN.md section 10.
+_STEM_KERNELS = os.environ.get("MISEG_STEM_KERNELS", "0") == "1"
 _BN_ACC = os.environ.get("MISEG_BN_ACC", "1") != "0"
 # The same for the backward's sums (two fixed-point tiers, miseg_bn_relu_bwd_dual_acc).  Built and measured, OFF: the reduce kernel's
 # blocks all finish together, so their atomics arrive as one burst on a few lines (+8 us per launch) and the apply prologue costs 5 us
@@ -161,6 +165,12 @@ def stem_input(image: Tensor, dtype) -> Tensor:
     if pre is not None and pre[0] == dtype and pre[1].shape[0] == image.shape[0]:
         return pre[1]
     b, cin, h, w = image.shape
+    if _STEM_KERNELS and cin == 1 and image.dtype == torch.float32 and image.is_contiguous() and dtype in (torch.bfloat16, torch.float16):
+        # the stem's own kernels read the fp32 image itself (and round it as they read): the padded operand is only DESCRIBED -- an
+        # uninitialised tensor of its shape and type that carries the image; conv_bn_relu fills it in if it takes the MFMA path after all
+        out = empty_nhwc(b, vec_of(dtype), h, w, dtype, image.device)
+        out._miseg_stem_f32 = image
+        return out
     image = as_nhwc(image.float())
     cp = vec_of(dtype)
     cp = ((cin + cp - 1) // cp) * cp
@@ -292,12 +302,21 @@ class _ConvBNReLU(torch.autograd.Function):
         # the stem: one image channel read as a whole (zero-padded) channel vector; the weight keeps its own shape, the pack kernel pads
         assert weight.shape[1] == c0 + c1 or (x1 is None and weight.shape[1] < c0), (weight.shape, c0, c1)
         weight = weight.contiguous().float()
-        packed = _pack(weight, dtype, 0, cin=c0 + c1)
+        # the stem (one image channel, padded to a channel vector): its own kernels, no matrix cores (miseg_conv3x3_stem_fwd / _wgrad)
+        image = getattr(x0, "_miseg_stem_f32", None)       # stem_input's descriptor: x0 itself is uninitialised
+        stem = bool(_STEM_KERNELS and x1 is None and not ups0 and weight.shape[1] == 1 and c0 > 1 and
+                    query("miseg_conv3x3_stem_supported", _DT[dtype], 1, c0, cout))
+        packed = None if stem else _pack(weight, dtype, 0, cin=c0 + c1)
         raw = empty_nhwc(n, cout, h, w, dtype, dev)
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)
         counter = SYNC_COUNTERS.take(dev) if training and query("miseg_conv3x3_bn_fwd_fusable", _DT[dtype], c0 + c1, n, h, w, cout) else None
         acc = None
-        if training and counter is None and _BN_ACC and query("miseg_conv3x3_fwd_acc_supported", _DT[dtype], c0 + c1, n, h, w, cout):
+        if stem and training and (counter is not None or not _BN_ACC):
+            stem, packed = False, _pack(weight, dtype, 0, cin=c0 + c1)       # (the stem kernel hands its statistics to the accumulator only)
+        if image is not None and not stem:                                  # the MFMA path after all: materialise the padded operand
+            call("miseg_cast_pad", _stream(), _ptr(image), n * h * w, 1, _DT[dtype], _ptr(x0), c0)
+            image = None
+        if training and counter is None and _BN_ACC and (stem or query("miseg_conv3x3_fwd_acc_supported", _DT[dtype], c0 + c1, n, h, w, cout)):
             # the statistics leave the convolution as fixed-point atomic adds into one [2 C] accumulator that the step block's upload
             # zeroed; the apply kernel turns them into coefficients itself: no partial rows, no finalize launch
             io = stepio.current()
@@ -311,7 +330,11 @@ class _ConvBNReLU(torch.autograd.Function):
             parts, stats = 0, None
         es = x0.element_size()
         work = (18.0 * (c0 + c1) * cout * n * h * w, float(es) * n * h * w * (c0 / (4 ** ups0) + c1 / (4 ** ups1) + cout))
-        if acc is not None:
+        if stem:
+            call("miseg_conv3x3_stem_fwd", _stream(), _DT[dtype], _ptr(image if image is not None else x0), int(image is not None), 1 if image is not None else c0,
+                 n, h, w, _ptr(weight), 1, cout, _ptr(raw), _ptr(acc),
+                 work=(18.0 * cout * n * h * w, float(es) * n * h * w * (c0 + cout)), tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
+        elif acc is not None:
             call("miseg_conv3x3_fwd_acc", _stream(), _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(packed), cout, _ptr(raw),
                  _ptr(acc), work=work, tag=f"conv3x3_fwd[{h}x{w},{c0 + c1}->{cout}]")
         elif counter is not None:     # the conv's last block turns the partial sums into `saved` / the running statistics itself
@@ -338,6 +361,7 @@ class _ConvBNReLU(torch.autograd.Function):
         ctx.save_for_backward(x0, x1, weight, gamma, raw, y, saved)
         ctx.param_refs = (weight, gamma, beta)   # the Parameter objects (flat-gradient slots hang off them)
         ctx.cfg = (training, ups0, ups1, want_pool, c0, c1, n, h, w, cout)
+        ctx.stem, ctx.image = stem, (image if stem else None)
         if rec is not None:
             rec.raw, rec.saved, rec.shape = raw, saved, (n, cout, h, w)
         ctx.recs = (rec, rec0, rec1)
@@ -419,21 +443,28 @@ class _ConvBNReLU(torch.autograd.Function):
                     # backward() returns -- gradient accumulation, clip_grad_norm_, inspection -- not only after collect()
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_streams)
                 wait_stream(side, cur)        # graw is produced above
-                for t in (graw, x0, x1):      # keep their memory from being recycled under the side stream
+                for t in (graw, x0, x1, getattr(ctx, "image", None)):      # keep their memory from being recycled under the side stream
                     keep(t, side)
                 _wgrad_dirty.add(dev)
             # launched on the side stream by HANDLE (entering the `torch.cuda.stream` context costs 15-20 us of host time, 22 times per
             # backward pass); the workspace comes from the current stream's pool and is handed to the side stream like the operands
-            ws2 = _ws(query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
+            stem_wg = bool(ctx.stem and not _FUSE_BN_BWD)
+            ws2 = _ws(query("miseg_conv3x3_stem_wgrad_ws_bytes", cout) if stem_wg else query("miseg_conv3x3_wgrad_ws_bytes", n, h, w, c0 + c1, cout), dev)
             # the stem's weight has fewer input channels than the channel vector its activation was padded to: the kernel computes the
             # padded gradient, a slice of it is the parameter's
-            gw_full = gw if weight.shape[1] == c0 + c1 else torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dev)
+            gw_full = gw if (weight.shape[1] == c0 + c1 or stem_wg) else torch.empty((cout, c0 + c1, 3, 3), dtype=torch.float32, device=dev)
             if side is not None:
                 keep(ws2, side)
                 if gw_full is not gw:
                     keep(gw_full, side)
 
             def launch(stream_handle):
+                if stem_wg:      # the last kernel of the backward pass: a pixel-per-thread kernel, gw [cout][1][3][3] written directly
+                    img = ctx.image
+                    call("miseg_conv3x3_stem_wgrad", stream_handle, _DT[dtype], _ptr(img if img is not None else x0), int(img is not None),
+                         1 if img is not None else c0, n, h, w, _ptr(graw), cout, _ptr(gw), _ptr(ws2), ws2.numel(),
+                         work=(18.0 * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + cout)), tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")
+                    return
                 call("miseg_conv3x3_wgrad", stream_handle, _DT[dtype], _ptr(x0), c0, ups0, _ptr(x1), c1, ups1, n, h, w, _ptr(graw), cout, _ptr(gw_full),
                      _ptr(ws2), ws2.numel(), work=(18.0 * (c0 + c1) * cout * n * h * w, float(raw.element_size()) * n * h * w * (c0 + c1 + cout)),
                      tag=f"conv3x3_wgrad[{h}x{w},{c0 + c1}->{cout}]")

@@ -306,6 +306,52 @@ def test_bn_statistics_as_fixed_point_accumulators_equal_the_finalize_launch(sha
         assert err <= tol, (name, err)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(4, 64, 96, 16), (3, 50, 46, 16), (2, 256, 256, 16), (5, 33, 20, 32)])
+def test_stem_kernels_equal_the_mfma_path_and_the_fp32_reference(shape, dtype, monkeypatch):
+    """The stem's own kernels (miseg_conv3x3_stem_fwd / _wgrad: a pixel and four output channels per thread, no matrix cores) against the
+    streaming MFMA convolution + tiled weight gradient on the padded channel vector, and against torch in fp32 on the same 16-bit operands:
+    same products, fp32 sums in another order -> outputs within one 16-bit ulp, statistics 2e-6, parameter gradients 5e-3 relative L2;
+    training and evaluation mode, ragged sizes."""
+    from miseg_amd import unet_ops
+    n, h, w, cout = shape
+    img = T(synth.normal(f"stem/{shape}/x", (n, 1, h, w))).to(DEV).to(dtype)
+    xpad = nhwc(torch.cat([img, torch.zeros(n, 7, h, w, device=DEV, dtype=dtype)], 1))
+    wt = T(synth.normal(f"stem/{shape}/w", (cout, 1, 3, 3), scale=(2.0 / 9) ** 0.5)).to(DEV)
+    cot = T(synth.normal(f"stem/{shape}/cot", (n, cout, h, w))).to(DEV)
+
+    img32 = img.float().contiguous()           # (16-bit values: the descriptor form rounds them to themselves)
+
+    def run(stem, training=True, descriptor=False):
+        monkeypatch.setattr(unet_ops, "_STEM_KERNELS", stem)
+        bn = {k: v.to(DEV) for k, v in make_bn(cout, f"stem/{shape}/bn").items()}
+        wd = wt.clone().requires_grad_(True)
+        gd, bd = bn["weight"].clone().requires_grad_(True), bn["bias"].clone().requires_grad_(True)
+        xin = unet_ops.stem_input(img32, dtype) if descriptor else xpad        # descriptor: what the network passes (the fp32 image rides along)
+        assert (getattr(xin, "_miseg_stem_f32", None) is not None) == descriptor
+        y, _ = unet_ops.conv_bn_relu(xin, None, wd, gd, bd, bn["running_mean"], bn["running_var"], bn["nbt"], training, 0, 0, False)
+        (y.float() * cot).sum().backward()
+        return [t.detach().float().cpu() for t in (y, bn["running_mean"], bn["running_var"], gd.grad, bd.grad, wd.grad)]
+
+    for training in (True, False):
+        got, ref, dsc = run(True, training), run(False, training), run(True, training, descriptor=True)
+        for a, d in zip(got, dsc):
+            assert torch.equal(a, d)            # the stem kernels on the padded operand and on the fp32 image: the same numbers
+        for a, b, name in zip(got, ref, ("y", "running_mean", "running_var", "ggamma", "gbeta", "gw")):
+            if name == "y":
+                assert (a - b).abs().max().item() <= 1.6e-2 * b.abs().max().item(), name
+            elif name.startswith("running"):
+                assert (a - b).abs().max().item() <= 2e-6 * (b.abs().max().item() + 1.0), name
+            else:
+                assert (a - b).norm().item() <= 5e-3 * (b.norm().item() + 1e-30), (name, (a - b).norm().item() / b.norm().item())
+    # fp32 torch on the same 16-bit operands (weights rounded as the kernels round them)
+    w16 = wt.to(dtype).float()
+    y32, _, rm, rv = ref_layer(img.float(), w16, {k: v.to(DEV) for k, v in make_bn(cout, f"stem/{shape}/bn").items()}, True, False)
+    got = run(True, True)
+    assert (got[0] - y32.cpu()).abs().max().item() <= 1.6e-2 * y32.abs().max().item()
+    assert (got[1] - rm.cpu()).abs().max().item() <= 1e-5 and (got[2] - rv.cpu()).abs().max().item() <= 1e-5 * float(rv.abs().max())
+
+
 def test_bn_statistics_accumulator_poisoned_by_a_non_finite_activation():
     """A non-finite (or absurdly large) block sum must not turn into a plausible statistic: the accumulator is poisoned and the batch
     statistics come out NaN, as with the float path (the kernels' ReLU is fmaxf(v, 0): the activations themselves read 0 either way)."""
@@ -536,10 +582,17 @@ def test_concat_data_gradient_in_one_launch_equals_the_two_sliced_launches(n, h,
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("shape", [(48, 1, 256, 256), (3, 1, 50, 46), (2, 3, 20, 36)])
-def test_stem_input_is_the_cast_image_padded_with_zero_channels(shape, dtype):
-    """miseg_cast_pad (both kernels: the one-channel 16-byte-vector form the bench runs, and the generic one) bit for bit."""
+def test_stem_input_is_the_cast_image_padded_with_zero_channels(shape, dtype, monkeypatch):
+    """miseg_cast_pad (both kernels: the one-channel 16-byte-vector form, and the generic one) bit for bit.  (With the stem's own kernels
+    -- the shipped path for a one-channel image in 16-bit storage -- stem_input only DESCRIBES the operand: same shape and type, the
+    fp32 image attached; that form is checked by test_stem_kernels_equal_the_mfma_path_and_the_fp32_reference.)"""
     from miseg_amd import unet_ops
     img = T(synth.normal("stem_input/img", shape)).to(DEV)
+    if shape[1] == 1 and dtype != torch.float32:
+        monkeypatch.setattr(unet_ops, "_STEM_KERNELS", True)
+        desc = unet_ops.stem_input(img, dtype)
+        assert desc.dtype == dtype and tuple(desc.shape) == (shape[0], unet_ops.vec_of(dtype), shape[2], shape[3]) and desc._miseg_stem_f32 is img
+    monkeypatch.setattr(unet_ops, "_STEM_KERNELS", False)
     out = unet_ops.stem_input(img, dtype)
     vec = unet_ops.vec_of(dtype)
     cp = (shape[1] + vec - 1) // vec * vec
