@@ -1570,15 +1570,59 @@ __global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict
     reduce_partials_block(partials, nparts, (size_t)len, len, Split2Out{d0, n0, d1}, [](int e) { return (size_t)e; });
 }
 
-// ---- The stem (one image channel in, padded to a channel vector) without matrix cores -- an experiment, OFF by default
-// (MISEG_STEM_KERNELS=1).  `conv3x3_stream_kernel` treats the padded vector as 8 (of 32) input channels: 31 of 32
-// multiplies are by zero, and the launch takes 50 us at 256 x 256 for a 100 MB store; its weight gradient (59 us) is the LAST kernel of
-// the backward pass, alone on the GPU, i.e. all of it is step tail.  Measured: these kernels take 56 / 57 + 8 us -- the per-row
-// staging (load -> barrier -> compute, no prefetch) is latency-bound; nine direct loads per thread are worse (122 / 140 us).
-// Here a thread owns one pixel and four output channels: nine bf16 x bf16 products per output (exact in fp32, accumulated by FMA in tap order), 8-byte stores that
+// ---- The stem (one image channel in) without matrix cores (MISEG_STEM_KERNELS=0: the MFMA path).
+// `conv3x3_stream_kernel` treats the padded channel vector as 8 (of 32) input channels: 31 of 32 multiplies are by zero, the launch takes
+// 50 us at 256 x 256 for a 100 MB store, and the padded operand has to be written first (15 us); its weight gradient (59 + 10 us) is the
+// LAST kernel of the backward pass, alone on the GPU, i.e. all of it is step tail.  These kernels read the fp32 image itself and take
+// 50 / 52 + 7 us (rows through a prefetched LDS ring; staging three rows per output row without prefetch: 56 / 57; nine direct loads per
+// thread: 122 / 140; on the padded operand, 16-byte stride: 148 / 156).
+// A thread owns one pixel and four output channels: nine bf16 x bf16 products per output (exact in fp32, accumulated by FMA in tap order), 8-byte stores that
 // are contiguous across the lanes of a pixel; statistics from the fp32 accumulators as everywhere.  x: [N][H][W][CP] (channel 0 is the
 // image), w: the fp32 master [Cout][Cw][3][3] (Cw >= 1: only input channel 0 is read), rounded to the storage type as the packed
 // weights of the MFMA path are.
+// The input rows of a block's run of output rows, as a ring of four LDS rows (+ one row of zeros): an output row reads rows r - 1, r,
+// r + 1; row r + 2 is committed from registers behind its compute and row r + 3 is already in flight (one barrier per row, the
+// global round trip behind a whole row's arithmetic).  Rows of the neighbouring image / outside the image read the zero row.
+template <typename T, typename TX, int NPRE>
+struct StemRing {
+    unsigned short* buf;      // [5][RB]: slots 0..3 the ring, slot 4 zeros
+    const TX* x;
+    int RB, W, CP, rows;
+    unsigned short pre[NPRE];
+    __device__ __forceinline__ void fetch(int rin) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int c = (int)threadIdx.x + 256 * k - 1;
+            T v = from_f32<T>(0.f);
+            if ((unsigned)rin < (unsigned)rows && (unsigned)c < (unsigned)W) v = from_f32<T>(to_f32(x[((size_t)rin * W + c) * CP]));    // an fp32 image is rounded here
+            pre[k] = *reinterpret_cast<const unsigned short*>(&v);
+        }
+    }
+    __device__ __forceinline__ void commit(int rin) {
+        unsigned short* d = buf + ((rin + 1) & 3) * RB;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i < RB) d[i] = pre[k];
+        }
+    }
+    __device__ __forceinline__ const unsigned short* row(int rin, bool inside) const { return inside ? buf + ((rin + 1) & 3) * RB : buf + 4 * RB; }
+    // rows r0 - 1, r0, r0 + 1 staged, r0 + 2 in flight
+    __device__ __forceinline__ void start(int r0) {
+        for (int i = threadIdx.x; i < RB; i += 256) buf[4 * RB + i] = 0;
+        for (int d = -1; d <= 1; ++d) { fetch(r0 + d); commit(r0 + d); }
+        fetch(r0 + 2);
+        __syncthreads();
+    }
+    // after the compute of row r: row r + 2 becomes readable, row r + 3 takes off
+    __device__ __forceinline__ void advance(int r) {
+        commit(r + 2);
+        fetch(r + 3);
+        __syncthreads();
+    }
+};
+constexpr int kStemPre = 4;       // W + 2 <= 1024
+
 template <typename T, typename TX>
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const TX* __restrict__ x, int CP, int N, int H, int W, const float* __restrict__ w, int Cw,
                                                             int Cout, T* __restrict__ out, unsigned long long* __restrict__ acc) {
@@ -1589,29 +1633,21 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const TX* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) wr[tap][r] = to_f32(from_f32<T>(w[((size_t)(g * 4 + r) * Cw) * 9 + tap]));
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    // A block walks whole image rows (row = n * H + h: block-uniform, so is h); the three input rows a row needs are staged in LDS first,
-    // one 2-byte load per pixel and row (read per thread, the nine taps of a pixel were 36 narrow loads: the kernel ran at the
-    // load unit's instruction rate, 148 us).  Rows / columns outside the image are zeros in the buffer.
-    extern __shared__ unsigned short stem_rows[];        // [3][W + 2]
-    const int rows = N * H, c0 = threadIdx.x / G, RB = W + 2;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    // a block walks a contiguous run of image rows (row = n * H + h: block-uniform, so is h), its threads the row's pixels
+    extern __shared__ unsigned short stem_rows[];        // [5][W + 2]
+    const int rows = N * H, c0 = threadIdx.x / G, per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r_begin = blockIdx.x * per, r_end = min(rows, r_begin + per);
+    StemRing<T, TX, kStemPre> ring{stem_rows, x, W + 2, W, CP, rows, {}};
+    if (r_begin < r_end) ring.start(r_begin);
+    for (int row = r_begin; row < r_end; ++row) {
       const int h = row % H;
-      {
-          __syncthreads();
-          for (int i = threadIdx.x; i < 3 * RB; i += 256) {
-              const int rr = i / RB, c = i - rr * RB - 1, hh = h + rr - 1;
-              T v = from_f32<T>(0.f);
-              if ((unsigned)hh < (unsigned)H && (unsigned)c < (unsigned)W) v = from_f32<T>(to_f32(x[((size_t)(row + rr - 1) * W + c) * CP]));
-              stem_rows[i] = *reinterpret_cast<const unsigned short*>(&v);
-          }
-          __syncthreads();
-      }
+      const unsigned short* rp[3] = {ring.row(row - 1, h > 0), ring.row(row, true), ring.row(row + 1, h < H - 1)};
       for (int wq = c0; wq < W; wq += ppb) {
         const size_t p = (size_t)row * W + wq;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const float v = bf16_bits_to_f32(stem_rows[(tap / 3) * RB + wq + tap % 3]);
+            const float v = bf16_bits_to_f32(rp[tap / 3][wq + tap % 3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = fmaf(v, wr[tap][r], a[r]);
         }
@@ -1620,6 +1656,7 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const TX* __restrict
         for (int r = 0; r < 4; ++r) { o4[r] = from_f32<T>(a[r]); s1[r] += a[r]; s2[r] += a[r] * a[r]; }
         *reinterpret_cast<uint2*>(out + p * Cout + g * 4) = *reinterpret_cast<const uint2*>(o4);
       }
+      ring.advance(row);
     }
     if (acc) {       // block sums per channel (fixed order), then the fixed-point accumulator (common.h bn_acc_add)
         __shared__ float sred[256][8];
@@ -1635,8 +1672,8 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const TX* __restrict
     }
 }
 
-// gw[co][tap] = sum_px graw[px][co] * x[px + tap]: the same thread map, 36 accumulators per thread over the block's pixels, one partial
-// vector [Cout * 9] per block (summed by stem_wgrad_sum_kernel in fixed order: deterministic)
+// gw[co][tap] = sum_px graw[px][co] * x[px + tap]: the same thread map and row ring, 36 accumulators per thread over the block's pixels,
+// one partial vector [Cout * 9] per block (summed by stem_wgrad_sum_kernel in fixed order: deterministic)
 template <typename T, typename TX>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ x, int CP, int N, int H, int W, const T* __restrict__ graw, int Cout,
                                                          float* __restrict__ partials) {
@@ -1646,21 +1683,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ 
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[tap][r] = 0.f;
-    extern __shared__ float swr[];      // [256][37]: the threads' 36 sums (odd stride: conflict-free column reads); behind it the three staged input rows
-    unsigned short* stem_rows = reinterpret_cast<unsigned short*>(swr + 256 * 37);       // [3][W + 2]
-    const int rows = N * H, c0 = threadIdx.x / G, RB = W + 2;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    extern __shared__ float swr[];      // [256][37]: the threads' 36 sums (odd stride: conflict-free column reads); behind it the row ring
+    const int rows = N * H, c0 = threadIdx.x / G, per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r_begin = blockIdx.x * per, r_end = min(rows, r_begin + per);
+    StemRing<T, TX, kStemPre> ring{reinterpret_cast<unsigned short*>(swr + 256 * 37), x, W + 2, W, CP, rows, {}};
+    if (r_begin < r_end) ring.start(r_begin);
+    for (int row = r_begin; row < r_end; ++row) {
       const int h = row % H;
-      {
-          __syncthreads();
-          for (int i = threadIdx.x; i < 3 * RB; i += 256) {
-              const int rr = i / RB, c = i - rr * RB - 1, hh = h + rr - 1;
-              T v = from_f32<T>(0.f);
-              if ((unsigned)hh < (unsigned)H && (unsigned)c < (unsigned)W) v = from_f32<T>(to_f32(x[((size_t)(row + rr - 1) * W + c) * CP]));
-              stem_rows[i] = *reinterpret_cast<const unsigned short*>(&v);
-          }
-          __syncthreads();
-      }
+      const unsigned short* rp[3] = {ring.row(row - 1, h > 0), ring.row(row, true), ring.row(row + 1, h < H - 1)};
       for (int wq = c0; wq < W; wq += ppb) {
         const size_t p = (size_t)row * W + wq;
         const uint2 gq = *reinterpret_cast<const uint2*>(graw + p * Cout + g * 4);
@@ -1669,11 +1699,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ 
         const float gv[4] = {to_f32(g4[0]), to_f32(g4[1]), to_f32(g4[2]), to_f32(g4[3])};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const float v = bf16_bits_to_f32(stem_rows[(tap / 3) * RB + wq + tap % 3]);
+            const float v = bf16_bits_to_f32(rp[tap / 3][wq + tap % 3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[tap][r] = fmaf(gv[r], v, a[tap][r]);
         }
       }
+      ring.advance(row);
     }
     __syncthreads();
 #pragma unroll
@@ -1691,7 +1722,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ 
 __global__ __launch_bounds__(256) void stem_wgrad_sum_kernel(const float* __restrict__ partials, int nparts, int len, float* __restrict__ gw) {
     reduce_partials_block(partials, nparts, (size_t)len, len, gw, [](int e) { return (size_t)e; });
 }
-constexpr int kStemBlocks = 1024;
+constexpr int kStemBlocksMax = 4096;
+static const int kStemBlocks = [] { const char* e = getenv("MISEG_STEM_BLOCKS"); return e ? std::min(kStemBlocksMax, std::max(1, atoi(e))) : 1024; }();      // (ws sized for kStemBlocksMax)
 
 static inline int tile_w(int64_t W) { return W >= 32 ? 32 : 16; }
 
@@ -2035,19 +2067,19 @@ extern "C" int miseg_conv3x3_stem_fwd(void* stream, int dt, const void* x, int x
     MISEG_REQUIRE(x && w && out && N > 0 && H > 0 && W > 0, "conv3x3_stem_fwd: bad args");
     MISEG_REQUIRE(miseg_conv3x3_stem_supported(dt, Cin_weight, CP, Cout), "conv3x3_stem_fwd: 16-bit storage, one weight input channel, Cout in {4, 8, 16, 32, 64}");
     MISEG_REQUIRE(!acc_or_null || ((uintptr_t)acc_or_null & 7) == 0, "conv3x3_stem_fwd: the accumulator must be 8-byte aligned");
-    MISEG_REQUIRE(W <= 4096, "conv3x3_stem_fwd: rows of at most 4096 pixels");
-    const unsigned nb = (unsigned)std::min<int64_t>(N * H, kStemBlocks);
+    MISEG_REQUIRE(W + 2 <= 256 * kStemPre, "conv3x3_stem_fwd: rows of at most %d pixels", 256 * kStemPre - 2);
+    const unsigned nb = (unsigned)std::min<int64_t>(N * H, (int64_t)kStemBlocks);
     if (x_f32)
-        hipLaunchKernelGGL((stem_conv_fwd_kernel<bf16, float>), dim3(nb), dim3(256), (size_t)3 * (W + 2) * 2, as_stream(stream), (const float*)x, (int)CP, (int)N, (int)H, (int)W, w,
+        hipLaunchKernelGGL((stem_conv_fwd_kernel<bf16, float>), dim3(nb), dim3(256), (size_t)5 * (W + 2) * 2, as_stream(stream), (const float*)x, (int)CP, (int)N, (int)H, (int)W, w,
                            (int)Cin_weight, (int)Cout, (bf16*)out, static_cast<unsigned long long*>(acc_or_null));
     else
-        hipLaunchKernelGGL((stem_conv_fwd_kernel<bf16, bf16>), dim3(nb), dim3(256), (size_t)3 * (W + 2) * 2, as_stream(stream), (const bf16*)x, (int)CP, (int)N, (int)H, (int)W, w,
+        hipLaunchKernelGGL((stem_conv_fwd_kernel<bf16, bf16>), dim3(nb), dim3(256), (size_t)5 * (W + 2) * 2, as_stream(stream), (const bf16*)x, (int)CP, (int)N, (int)H, (int)W, w,
                            (int)Cin_weight, (int)Cout, (bf16*)out, static_cast<unsigned long long*>(acc_or_null));
     MISEG_LAUNCH_CHECK("stem_conv_fwd_kernel");
     return MISEG_OK;
 }
 
-extern "C" int64_t miseg_conv3x3_stem_wgrad_ws_bytes(int64_t Cout) { return (int64_t)kStemBlocks * Cout * 9 * 4; }
+extern "C" int64_t miseg_conv3x3_stem_wgrad_ws_bytes(int64_t Cout) { return (int64_t)kStemBlocksMax * Cout * 9 * 4; }
 
 extern "C" int miseg_conv3x3_stem_wgrad(void* stream, int dt, const void* x, int x_f32, int64_t CP, int64_t N, int64_t H, int64_t W, const void* graw,
                                         int64_t Cout, float* gw, void* ws, int64_t ws_bytes) {
@@ -2056,14 +2088,14 @@ extern "C" int miseg_conv3x3_stem_wgrad(void* stream, int dt, const void* x, int
     MISEG_REQUIRE(x && graw && gw && ws && N > 0 && H > 0 && W > 0, "conv3x3_stem_wgrad: bad args");
     MISEG_REQUIRE(miseg_conv3x3_stem_supported(dt, 1, CP, Cout), "conv3x3_stem_wgrad: 16-bit storage, Cout in {4, 8, 16, 32, 64}");
     MISEG_REQUIRE(ws_bytes >= miseg_conv3x3_stem_wgrad_ws_bytes(Cout), "conv3x3_stem_wgrad: workspace too small");
-    MISEG_REQUIRE(W <= 4096, "conv3x3_stem_wgrad: rows of at most 4096 pixels");
-    const unsigned nb = (unsigned)std::min<int64_t>(N * H, kStemBlocks);
+    MISEG_REQUIRE(W + 2 <= 256 * kStemPre, "conv3x3_stem_wgrad: rows of at most %d pixels", 256 * kStemPre - 2);
+    const unsigned nb = (unsigned)std::min<int64_t>(N * H, (int64_t)kStemBlocks);
     hipStream_t st = as_stream(stream);
     if (x_f32)
-        hipLaunchKernelGGL((stem_wgrad_kernel<bf16, float>), dim3(nb), dim3(256), (size_t)256 * 37 * 4 + (size_t)3 * (W + 2) * 2, st, (const float*)x, (int)CP, (int)N, (int)H, (int)W,
+        hipLaunchKernelGGL((stem_wgrad_kernel<bf16, float>), dim3(nb), dim3(256), (size_t)256 * 37 * 4 + (size_t)5 * (W + 2) * 2, st, (const float*)x, (int)CP, (int)N, (int)H, (int)W,
                            (const bf16*)graw, (int)Cout, (float*)ws);
     else
-        hipLaunchKernelGGL((stem_wgrad_kernel<bf16, bf16>), dim3(nb), dim3(256), (size_t)256 * 37 * 4 + (size_t)3 * (W + 2) * 2, st, (const bf16*)x, (int)CP, (int)N, (int)H, (int)W,
+        hipLaunchKernelGGL((stem_wgrad_kernel<bf16, bf16>), dim3(nb), dim3(256), (size_t)256 * 37 * 4 + (size_t)5 * (W + 2) * 2, st, (const bf16*)x, (int)CP, (int)N, (int)H, (int)W,
                            (const bf16*)graw, (int)Cout, (float*)ws);
     MISEG_LAUNCH_CHECK("stem_wgrad_kernel");
     const int len = (int)(Cout * 9);

@@ -65,10 +65,11 @@ _FUSE_BN_RED = True      # ... including the statistics pass in the producing da
 _RED_ONLY = os.environ.get("MISEG_BN_RED", "0") == "1" and not _FUSE_BN_BWD
 # 1 (default): the forward statistics leave the convolution as fixed-point atomic adds and the apply kernel finishes them itself
 # (miseg_conv3x3_fwd_acc / miseg_bn_relu_fwd_acc): 22 launches fewer per step.  0: one partial row per block + miseg_bn_finalize.
-# 1: the stem (one image channel) through its own pixel-per-thread kernels reading the fp32 image, instead of the streaming MFMA convolution
-# and the tiled weight gradient on a padded channel vector.  Built, parity-tested, not faster (56 vs 50 us forward, 57 + 8 vs 59 + 10 us
-# weight gradient; the padded operand's 15 us launch becomes 4): OFF.  DESIGN.md section 10.
-_STEM_KERNELS = os.environ.get("MISEG_STEM_KERNELS", "0") == "1"
+# The stem (one image channel) through its own pixel-per-thread kernels reading the fp32 image, instead of the streaming MFMA convolution
+# and the tiled weight gradient on a padded channel vector: the kernels themselves are on a par (50 vs 50 us forward, 52 + 7 vs 59 + 10 us
+# weight gradient -- the step's last kernel), the padded operand's 15 us launch becomes 4: -0.02 ms per step.  0: the MFMA path.
+_STEM_KERNELS = os.environ.get("MISEG_STEM_KERNELS", "1") != "0"
+_STEM_MAX_W = 1022                  # the stem kernels keep whole image rows (+ halo) in 4 x 256 registers
 _BN_ACC = os.environ.get("MISEG_BN_ACC", "1") != "0"
 # The same for the backward's sums (two fixed-point tiers, miseg_bn_relu_bwd_dual_acc).  Built and measured, OFF: the reduce kernel's
 # blocks all finish together, so their atomics arrive as one burst on a few lines (+8 us per launch) and the apply prologue costs 5 us
@@ -165,7 +166,7 @@ def stem_input(image: Tensor, dtype) -> Tensor:
     if pre is not None and pre[0] == dtype and pre[1].shape[0] == image.shape[0]:
         return pre[1]
     b, cin, h, w = image.shape
-    if _STEM_KERNELS and cin == 1 and image.dtype == torch.float32 and image.is_contiguous() and dtype in (torch.bfloat16, torch.float16):
+    if _STEM_KERNELS and cin == 1 and w <= _STEM_MAX_W and image.dtype == torch.float32 and image.is_contiguous() and dtype in (torch.bfloat16, torch.float16):
         # the stem's own kernels read the fp32 image itself (and round it as they read): the padded operand is only DESCRIBED -- an
         # uninitialised tensor of its shape and type that carries the image; conv_bn_relu fills it in if it takes the MFMA path after all
         out = empty_nhwc(b, vec_of(dtype), h, w, dtype, image.device)
@@ -304,7 +305,7 @@ class _ConvBNReLU(torch.autograd.Function):
         weight = weight.contiguous().float()
         # the stem (one image channel, padded to a channel vector): its own kernels, no matrix cores (miseg_conv3x3_stem_fwd / _wgrad)
         image = getattr(x0, "_miseg_stem_f32", None)       # stem_input's descriptor: x0 itself is uninitialised
-        stem = bool(_STEM_KERNELS and x1 is None and not ups0 and weight.shape[1] == 1 and c0 > 1 and
+        stem = bool(_STEM_KERNELS and x1 is None and not ups0 and weight.shape[1] == 1 and c0 > 1 and w <= _STEM_MAX_W and
                     query("miseg_conv3x3_stem_supported", _DT[dtype], 1, c0, cout))
         packed = None if stem else _pack(weight, dtype, 0, cin=c0 + c1)
         raw = empty_nhwc(n, cout, h, w, dtype, dev)

@@ -589,7 +589,6 @@ def test_stem_input_is_the_cast_image_padded_with_zero_channels(shape, dtype, mo
     from miseg_amd import unet_ops
     img = T(synth.normal("stem_input/img", shape)).to(DEV)
     if shape[1] == 1 and dtype != torch.float32:
-        monkeypatch.setattr(unet_ops, "_STEM_KERNELS", True)
         desc = unet_ops.stem_input(img, dtype)
         assert desc.dtype == dtype and tuple(desc.shape) == (shape[0], unet_ops.vec_of(dtype), shape[2], shape[3]) and desc._miseg_stem_f32 is img
     monkeypatch.setattr(unet_ops, "_STEM_KERNELS", False)
