@@ -15,7 +15,7 @@ int fail(int code, const char* fmt, ...) {
 }
 }  // namespace miseg_core
 
-extern "C" int miseg_version(void) { return 405; }   // round 4 (profiles/r04_pmc.json is keyed by this)
+extern "C" int miseg_version(void) { return 406; }   // round 4 (profiles/r04_pmc.json is keyed by this)
 extern "C" const char* miseg_last_error(void) { return miseg::last_error_buf(); }
 
 // ---- cross-stream ordering without a system-scope fence --------------------------------------------------------------------------

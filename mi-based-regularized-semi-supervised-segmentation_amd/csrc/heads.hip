@@ -282,7 +282,11 @@ __global__ __launch_bounds__(kHT) void head_local_fwd_mfma_kernel(const bf16* __
         if (live) {
             float* out = prob + (((size_t)s * M + m) * K) * HW + pix0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(out + (size_t)k * HW) = make_float4(z[0][k], z[1][k], z[2][k], z[3][k]);
+            for (int k = 0; k < K; ++k) {
+                // non-temporal: 839 MB that nothing re-reads from a cache
+                const f32x4 v4 = {z[0][k], z[1][k], z[2][k], z[3][k]};
+                __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(out + (size_t)k * HW));
+            }
         }
     }
     if (viol && live && nbad) atomicAdd(viol, nbad);

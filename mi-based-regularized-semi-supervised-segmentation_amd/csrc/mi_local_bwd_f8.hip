@@ -62,6 +62,9 @@
 #ifndef MISEG_F8_STAMP
 #define MISEG_F8_STAMP 0     // diagnostic build: per-phase s_memtime sums of every wave -> the tail of the workspace (scratch/f8_stamps.py)
 #endif
+#ifndef MISEG_F8_STORE_AUX
+#define MISEG_F8_STORE_AUX 0     // cache policy of the output stores (2 = non-temporal: measured)
+#endif
 #ifndef MISEG_F8_ABL
 #define MISEG_F8_ABL 0       // ablation builds (scratch): 1 = no per-row fetch / commit, 2 = no output stores
 #endif
@@ -577,11 +580,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void local_bwd_f8_kernel(const float
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = sc * done[nt][r] + (ACC ? old_m[nt][r] : 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)vo_m[nt], (int)(rowo + (unsigned)r * (unsigned)plane * 4u), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, (int)vo_m[nt], (int)(rowo + (unsigned)r * (unsigned)plane * 4u), MISEG_F8_STORE_AUX);
 #pragma unroll
                     for (int t = 0; t < RT; ++t) {
                         const float vr = sc * rem[t][nt][r] + (ACC ? old_r[t][nt][r] : 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), rso, (int)vo_r[t][nt], (int)(rowo + (unsigned)(16 + r) * (unsigned)plane * 4u), MISEG_F8_STORE_AUX);
                     }
                 }
             F8_STAMP(st_out)
